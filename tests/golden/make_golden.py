@@ -1,0 +1,187 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE in the build container (CPU).
+
+Run:  cd /root/repo && python tests/golden/make_golden.py
+Needs /root/reference (read-only) -- never runs on the GPU box.  The files it writes are data
+(inputs, weights of deliberately tiny model configurations, and the reference's outputs).
+
+Fixtures
+  msda_cases.npz       reference MSDA core (ms_deform_attn_func.py:67-87) on the reference's own
+                       test case (models/ops/test.py:21-26, seed 3) + cases with out-of-range
+                       sampling locations and a realistic slice
+  interp_cases.npz     F.interpolate nearest / bilinear(align_corners=False) at the odd size pairs
+                       the model hits (12x20->23x40, 23x40->11x20 ...)
+  e2e_swin_t_small.npz full ReferFormer.forward of the reference, real Swin-T architecture, T=3, 72x100
+                       (non-multiples of 4*7, odd merges), flags of scripts/dist_test_davis.sh; weights are
+                       tce_rvos_amd.weights.synth_state_dict (a function of key+shape+salt, not stored);
+                       frames = randn(seed); text encoder outputs stored (third-party RoBERTa, random init)
+  e2e_vswin_t_small.npz same with Video-Swin-T, T=9 (> window depth 8: temporal shift path)
+  e2e_swin_t_cfg2.npz  BASELINE config 2 at full size (T=5, 360x640): outputs only
+  statedict_*.json     the reference's state-dict keys/shapes (the drop-in checkpoint contract)
+  harness_cases.npz    caller harness H (inference_ytvos.py:238-250): logits+masks -> thresholded mask
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_msda():
+    rh.import_reference()
+    from models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    out = {}
+    # case 0: the reference's own test (models/ops/test.py:21-26,47-52), float path
+    N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    torch.manual_seed(3)
+    value = torch.rand(N, S, M, D) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    w = torch.rand(N, Lq, M, L, P) + 1e-5
+    w /= w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    cases = [(shapes, value, loc, w)]
+    # case 1: out-of-range locations, 2 frames
+    torch.manual_seed(11)
+    N, M, D, Lq, L, P = 2, 2, 32, 7, 2, 4
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, L, P, 2) * 1.6 - 0.3
+    w = torch.softmax(torch.randn(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    cases.append((shapes, value, loc, w))
+    # case 2: realistic slice (config-2 level shapes), 64 queries, out-of-range included
+    torch.manual_seed(12)
+    N, M, D, Lq, L, P = 1, 8, 32, 64, 4, 4
+    shapes = [(23, 40), (12, 20), (6, 10), (3, 5)]
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, L, P, 2) * 1.2 - 0.1
+    w = torch.softmax(torch.randn(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    cases.append((shapes, value, loc, w))
+    for i, (shapes, value, loc, w) in enumerate(cases):
+        o = ms_deform_attn_core_pytorch(value, shapes, loc, w)
+        out[f"c{i}_shapes"] = np.asarray(shapes, dtype=np.int64)
+        out[f"c{i}_value"] = _np(value)
+        out[f"c{i}_loc"] = _np(loc)
+        out[f"c{i}_w"] = _np(w)
+        out[f"c{i}_out"] = _np(o)
+    out["n_cases"] = np.asarray(len(cases))
+    np.savez_compressed(os.path.join(HERE, "msda_cases.npz"), **out)
+
+
+def gen_interp():
+    torch.manual_seed(5)
+    out = {}
+    pairs = [((12, 20), (23, 40)), ((23, 40), (45, 80)), ((45, 80), (90, 160)), ((23, 40), (11, 20)),
+             ((45, 80), (11, 20)), ((90, 160), (11, 20)), ((3, 4), (5, 7)), ((9, 13), (4, 6)), ((18, 25), (2, 3))]
+    for i, (a, b) in enumerate(pairs):
+        x = torch.randn(2, 3, *a)
+        out[f"p{i}_in"] = _np(x)
+        out[f"p{i}_size"] = np.asarray(b)
+        out[f"p{i}_nearest"] = _np(F.interpolate(x, size=b, mode="nearest"))
+        out[f"p{i}_bilinear"] = _np(F.interpolate(x, size=b, mode="bilinear", align_corners=False))
+    out["n_pairs"] = np.asarray(len(pairs))
+    np.savez_compressed(os.path.join(HERE, "interp_cases.npz"), **out)
+
+
+def _synth_inputs(T, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(T, 3, H, W, generator=g)
+
+
+def gen_e2e(name, backbone, T, H, W, seed, store_stages=True, stage_keys=None):
+    """Real architecture (Swin-T / Video-Swin-T, hidden 256, 4+4 layers), weights from
+    tce_rvos_amd.weights.synth_state_dict (keyed by state-dict name, so they need not be stored)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tce_rvos_amd.weights import load_synth_weights
+    args = rh.reference_args(backbone)
+    model = rh.build_reference_model(args, seed=0, roberta_layers=1)
+    load_synth_weights(model, salt=seed)
+    cap = {}
+    model.text_encoder.register_forward_hook(
+        lambda m, i, o: cap.update(hid=o.last_hidden_state.detach(), pool=o.pooler_output.detach()))
+    stages = {}
+    model.transformer.encoder.register_forward_hook(lambda m, i, o: stages.update(memory=o.detach()))
+    model.pixel_decoder.register_forward_hook(lambda m, i, o: stages.update(mask_features=o.detach()))
+    model.backbone[0].register_forward_hook(
+        lambda m, i, o: stages.update({f"backbone{k}": v.tensors.detach() for k, v in o.items()}))
+    frames = _synth_inputs(T, H, W, seed + 1)
+    with torch.no_grad():
+        out = model([frames], ["synthetic"], [{"size": torch.tensor([H, W])}])
+    fx = {"text_hidden": _np(cap["hid"]), "text_pooled": _np(cap["pool"]),
+          "thw": np.asarray([T, H, W]), "frames_seed": np.asarray(seed + 1), "weights_salt": np.asarray(seed)}
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points"):
+        fx["out_" + k] = _np(out[k])
+    fx["out_memory_sum"] = np.asarray(out["memory"].double().sum().item())
+    fx["out_memory_abs_sum"] = np.asarray(out["memory"].double().abs().sum().item())
+    for i, a in enumerate(out["aux_outputs"]):
+        for k, v in a.items():
+            if k != "pred_masks" or store_stages:
+                fx[f"aux{i}_{k}"] = _np(v)
+    if store_stages:
+        if stage_keys is None or "memory" in stage_keys:
+            fx["out_memory"] = _np(out["memory"])
+        for k, v in stages.items():
+            if stage_keys is None or k in stage_keys:
+                fx["stage_" + k] = _np(v)
+    fx["cfg_backbone"] = np.asarray(backbone)
+    np.savez_compressed(os.path.join(HERE, name), **fx)
+    print(name, "pred_masks", tuple(out["pred_masks"].shape), os.path.getsize(os.path.join(HERE, name)))
+    return model
+
+
+def gen_statedict_manifest(model, name):
+    import json
+    man = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()
+           if not k.startswith("text_encoder.")}
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+
+
+def gen_harness():
+    """inference_ytvos.py:238-250 restated with the same PyTorch primitives the caller uses."""
+    torch.manual_seed(21)
+    out = {}
+    for i, (t, q, h, w, H0, W0) in enumerate([(3, 5, 18, 25, 70, 99), (5, 5, 23, 40, 90, 160)]):
+        logits = torch.randn(1, t, q, 1)
+        masks = torch.randn(1, t, q, h, w) * 3
+        pred_logits = logits[0]
+        pred_masks = masks[0]
+        pred_scores = pred_logits.sigmoid().mean(0)
+        max_scores, _ = pred_scores.max(-1)
+        _, max_ind = max_scores.max(-1)
+        max_inds = max_ind.repeat(t)
+        pm = pred_masks[range(t), max_inds, ...].unsqueeze(0)
+        pm = F.interpolate(pm, size=(H0, W0), mode="bilinear", align_corners=False)
+        pm = (pm.sigmoid() > 0.5).squeeze(0)
+        out[f"h{i}_logits"] = _np(logits)
+        out[f"h{i}_masks"] = _np(masks)
+        out[f"h{i}_size"] = np.asarray([H0, W0])
+        out[f"h{i}_best"] = np.asarray(int(max_ind))
+        out[f"h{i}_out"] = _np(pm)
+    out["n_cases"] = np.asarray(2)
+    np.savez_compressed(os.path.join(HERE, "harness_cases.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_msda()
+    gen_interp()
+    gen_harness()
+    m = gen_e2e("e2e_swin_t_small.npz", "swin_t_p4w7", T=3, H=72, W=100, seed=0)
+    gen_statedict_manifest(m, "statedict_swin_t.json")
+    m = gen_e2e("e2e_vswin_t_small.npz", "video_swin_t_p4w7", T=9, H=72, W=100, seed=2,
+                stage_keys=("backbone1", "backbone3", "memory"))
+    gen_statedict_manifest(m, "statedict_vswin_t.json")
+    # BASELINE config 2 at full size: only the outputs are kept (inputs/weights regenerate from seeds)
+    gen_e2e("e2e_swin_t_cfg2.npz", "swin_t_p4w7", T=5, H=360, W=640, seed=4, store_stages=False)
+    print("done")
