@@ -1,0 +1,155 @@
+/* tce_rvos.h -- C ABI of libtce_rvos.so: the MI355X (gfx950) kernels behind the TCE-RVOS per-clip forward.
+ *
+ * Conventions ("C-ABI replacement for the native op"):
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; the caller owns all memory;
+ *   - activations are token-major / channels-last: [tokens, C] with tokens = (t, y, x);
+ *   - every entry takes the hipStream_t to launch on (as void*), is asynchronous, allocates nothing,
+ *     never synchronises, and is therefore legal inside hipGraph capture;
+ *   - return value: 0 = launched, <0 = rejected (bad shape / alignment) or launch error; the message is
+ *     available from tce_last_error().  No exceptions cross the boundary.
+ *
+ * Each entry cites the reference code (under /root/reference) whose arithmetic it replaces.
+ */
+#ifndef TCE_RVOS_H
+#define TCE_RVOS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tceStream; /* hipStream_t */
+
+int tce_abi_version(void);
+const char* tce_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *   C[M,N] = epi( (A[M,K] (+ A2[M,K])) @ W[N,K]^T + bias[N] )
+ *   epi:  act 0 none | 1 ReLU | 2 GELU(erf);  then res_mode 0 none | 1 "+ res[M,N]" | 2 "* res[M,N]".
+ * Replaces every nn.Linear / 1x1 Conv2d on the path, and (conv != 0) nn.Conv2d kxk as implicit GEMM over a
+ * channels-last image A[T,H,Wd,Cin] with W[N, kh*kw*Cin] (k = (ky*kw+kx)*Cin + c), M = T*Ho*Wo.
+ * batch > 1 runs `batch` independent problems (grid.z) with element strides sA.. (0 = shared).
+ * Reference: F.linear call sites, e.g. swin_transformer.py:133,151; tce_deformable_transformer.py:489,530;
+ * segmentation.py:84-86 (F.conv2d); tce_rvos.py:260,282.
+ * Requires K % 16 == 0, lda/lda2/ldw % 4 == 0 and 16-byte aligned A/A2/W.
+ */
+typedef struct {
+  const float* A;
+  const float* A2; /* optional addend to A (positional embedding), may be NULL */
+  const float* W;
+  const float* bias; /* may be NULL */
+  const float* res;  /* may be NULL when res_mode == 0 */
+  float* C;
+  int32_t M, N, K;
+  int32_t lda, lda2, ldw, ldc, ldres;
+  int32_t act, res_mode;
+  int32_t batch;
+  int64_t sA, sA2, sW, sBias, sC, sRes;
+  int32_t conv; /* 0 plain, 1 implicit-GEMM convolution */
+  int32_t T, H, Wd, Cin, Ho, Wo, kh, kw, stride, pad;
+} tceGemmArgs;
+int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
+
+/* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
+ * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */
+int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, float* out,
+                      int64_t M, int32_t C, float eps, tceStream stream);
+
+/* GroupNorm on channels-last x[T, HW, C] with G groups of C/G consecutive channels, optional ReLU.
+ * ws: device workspace of at least T*G*nsplit*3 floats (nsplit = tce_groupnorm_nsplit(HW)).
+ * Reference: nn.GroupNorm(32, 256) tce_rvos.py:81,86; nn.GroupNorm(8, C) segmentation.py:43. */
+int tce_groupnorm_nsplit(int32_t HW);
+int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
+                      int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream);
+
+/* Swin PatchEmbed: frames NCHW [T,3,H,W] -> zero-pad to x4 -> 4x4/s4 conv (w [C,3,4,4]) -> LayerNorm(C).
+ * out [T*Hp*Wp, C] token-major.  Reference: swin_transformer.py:427-443. */
+int tce_patch_embed_f32(const float* frames, const float* w, const float* b, const float* gamma,
+                        const float* beta, float* out, int32_t T, int32_t H, int32_t W, int32_t C, float eps,
+                        tceStream stream);
+
+/* Swin (shifted-)window attention core over tokens [T, H, W]: reads packed qkv [T*H*W, 3C] (q|k|v, heads of 32),
+ * applies zero-pad-to-x7 (padded tokens carry qkv = bias), cyclic shift, 7x7 windows, q*scale, relative position
+ * bias table[169, nH], the -100 shift mask, softmax, AV; writes out [T*H*W, C] in un-shifted token order.
+ * Reference: swin_transformer.py:50-77,127-158,214-249,370-388. */
+int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out, int32_t T,
+                        int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shift, tceStream stream);
+
+/* Swin PatchMerging front half: gather 2x2 neighbours in the order (0,0),(1,0),(0,1),(1,1) with odd-size zero
+ * padding, LayerNorm(4C).  x [T,H,W,C] -> out [T*ceil(H/2)*ceil(W/2), 4C].  Reference: swin_transformer.py:273-297. */
+int tce_patch_merge_ln_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t T, int32_t H,
+                           int32_t W, int32_t C, float eps, tceStream stream);
+
+/* Multi-head attention core, head_dim 32, fp32, online softmax:  O = softmax(Q K^T * scale) V per (batch, head).
+ * Q [batch][Lq] rows of ldq floats (head h at column h*32), likewise K, V, O.  kmask (optional, uint8
+ * [batch, Lk], non-zero = ignore key).  Reference: nn.MultiheadAttention call sites
+ * (tce_deformable_transformer.py:467,482,683; segmentation.py:352,366,459). */
+int tce_mha_f32(const float* Q, const float* K, const float* V, float* O, int32_t batch, int32_t nheads,
+                int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int64_t sQ, int64_t sK,
+                int64_t sV, int64_t sO, const uint8_t* kmask, float scale, tceStream stream);
+
+/* Multi-scale deformable attention forward -- the drop-in for the reference's only native op
+ * MultiScaleDeformableAttention_update.ms_deform_attn_forward (models/ops/src/vision.cpp:13-16,
+ * ms_deform_attn_cuda.cu:21-102, ms_deform_im2col_cuda.cuh:34-85,320-455):
+ *   value [N,S,M,D] (D == 32), spatial_shapes int64 [L,2] (H,W), level_start_index int64 [L] (both DEVICE),
+ *   sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]  ->  out [N,Lq,M*D]   (L*P <= 16). */
+int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                   const float* sampling_loc, const float* attn_weight, float* out, int32_t N,
+                                   int32_t S, int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P,
+                                   tceStream stream);
+
+/* Fused form used by the model: takes the raw projection output proj [N*Lq, M*L*P*3] = (sampling offsets
+ * [M,L,P,2] | attention logits [M,L*P]) and the reference points ref [N,Lq,ref_dim] (level-independent,
+ * valid_ratios == 1), does softmax over L*P, the offset normalisation (ref_dim 2: / (W_l,H_l); ref_dim 4:
+ * / P * wh * 0.5), and the bilinear gather.  Reference: ms_deform_attn.py:98-114 + the native kernel. */
+int tce_msda_fused_f32(const float* value, const float* proj, const float* ref, float* out,
+                       const int32_t* shapes_hw /* host, [L,2] */, int32_t N, int32_t S, int32_t M, int32_t Lq,
+                       int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
+
+/* Sine position map of an un-padded [T,h,w] grid, channels-last [T*h*w, 2F] (+ optional per-channel addend,
+ * the level embedding).  Reference: position_encoding.py:64-84 (normalize, scale 2*pi, the -0.5 shift). */
+int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, tceStream stream);
+
+/* Resampling on channels-last maps [T,h,w,C]:
+ *   nearest  : out[T,ho,wo,C] = in[.., floor(y*h/ho), floor(x*w/wo), :]  (PyTorch legacy 'nearest'), optional "+ add"
+ *   bilinear : align_corners=False, optional "+ add[T,ho,wo,C]"
+ * Reference: segmentation.py:212,241 (FPN up), :339-351 (VLBlock down), :360 (VLBlock up). */
+int tce_resize_nearest_f32(const float* in, const float* add, float* out, int32_t T, int32_t h, int32_t w, int32_t ho,
+                           int32_t wo, int32_t C, tceStream stream);
+int tce_resize_bilinear_f32(const float* in, const float* add, float* out, int32_t T, int32_t h, int32_t w,
+                            int32_t ho, int32_t wo, int32_t C, tceStream stream);
+
+/* Elementwise helpers (tiny tensors of the decoder / heads):
+ *   tce_add_f32        out = a + b (b broadcast with period nb elements)
+ *   tce_sigmoid_f32    out = sigmoid(x)
+ *   tce_box_refine_f32 out[n,4] = sigmoid(tmp[n,4] + inverse_sigmoid(ref[n,ref_dim]) on the first ref_dim coords)
+ *                      (tce_deformable_transformer.py:761-771, util/misc.py:555-559) */
+int tce_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t nb, tceStream stream);
+int tce_sigmoid_f32(const float* x, float* out, int64_t n, tceStream stream);
+int tce_box_refine_f32(const float* tmp, const float* ref, float* out, int32_t n, int32_t ref_dim, tceStream stream);
+
+/* Dynamic mask head (tce_rvos.py:426-510,536-599), evaluated for `nl` decoder levels at once without
+ * materialising the q-times repeated feature tensor:
+ *   tce_mask_pack_f32: params [nl, T*Q, npar] (layout [w0(8x(Cm+2)) | w1(8x8) | w2(1x8) | b0 | b1 | b2])
+ *                      -> w0f [T, nl*Q*8, Cm] (first-layer feature weights, GEMM operand) and
+ *                         tail [nl, T*Q, 112] (w0x[8], w0y[8], b0[8], w1[64], b1[8], w2[8], b2, pad)
+ *   (first layer = tce_gemm_f32 batched over frames: G[T, hw, nl*Q*8] = feats[T, hw, Cm] @ w0f[t]^T)
+ *   tce_mask_tail_f32: G + relative coords (ref*(img_w,img_h) - (x*4+2, y*4+2)) -> ReLU -> 8x8 -> ReLU -> 8->1
+ *                      -> masks [nl, T, Q, h, w]. */
+int tce_mask_pack_f32(const float* params, float* w0f, float* tail, int32_t nl, int32_t T, int32_t Q, int32_t Cm,
+                      tceStream stream);
+int tce_mask_tail_f32(const float* G, const float* tail, const float* refs /* [nl, T*Q, ref_ld] */, int32_t ref_ld,
+                      float* masks, int32_t nl, int32_t T, int32_t Q, int32_t h, int32_t w, float img_h, float img_w,
+                      int32_t stride_px, tceStream stream);
+
+/* hipGraph helpers so that the Python host can capture one forward and replay it. */
+int tce_graph_begin(tceStream stream);
+int tce_graph_end(tceStream stream, void** graph_exec_out);
+int tce_graph_launch(void* graph_exec, tceStream stream);
+int tce_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCE_RVOS_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libtce_rvos.so (the C ABI declared in include/tce_rvos.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent, importing this
+module's `lib()` raises.  Build it with `python -m tce_rvos_amd.build` / `__graft_entry__.build()`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtce_rvos.so")
+
+c_f = C.c_void_p  # device pointers travel as integers
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_f), ("A2", c_f), ("W", c_f), ("bias", c_f), ("res", c_f), ("C", c_f),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("lda2", i32), ("ldw", i32), ("ldc", i32), ("ldres", i32),
+                ("act", i32), ("res_mode", i32), ("batch", i32),
+                ("sA", i64), ("sA2", i64), ("sW", i64), ("sBias", i64), ("sC", i64), ("sRes", i64),
+                ("conv", i32), ("T", i32), ("H", i32), ("Wd", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32),
+                ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol of include/tce_rvos.h (tests check this)
+SIGNATURES = {
+    "tce_abi_version": (i32, []),
+    "tce_last_error": (C.c_char_p, []),
+    "tce_gemm_f32": (i32, [C.POINTER(GemmArgs), c_f]),
+    "tce_layernorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, c_f]),
+    "tce_groupnorm_nsplit": (i32, [i32]),
+    "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),
+    "tce_patch_embed_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
+    "tce_window_attn_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_patch_merge_ln_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
+    "tce_mha_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, c_f, f32, c_f]),
+    "tce_ms_deform_attn_forward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_msda_fused_f32": (i32, [c_f, c_f, c_f, c_f, C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_pos_sine2d_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
+    "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_resize_bilinear_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_add_f32": (i32, [c_f, c_f, c_f, i64, i64, c_f]),
+    "tce_sigmoid_f32": (i32, [c_f, c_f, i64, c_f]),
+    "tce_box_refine_f32": (i32, [c_f, c_f, c_f, i32, i32, c_f]),
+    "tce_mask_pack_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, c_f]),
+    "tce_mask_tail_f32": (i32, [c_f, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, f32, f32, i32, c_f]),
+    "tce_graph_begin": (i32, [c_f]),
+    "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
+    "tce_graph_launch": (i32, [C.c_void_p, c_f]),
+    "tce_graph_destroy": (i32, [C.c_void_p]),
+}
+
+_LIB = None
+
+
+class TceError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared object (once).  Raises if it is missing: there is no CPU / PyTorch fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TceError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is absent
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().tce_last_error().decode(errors="replace")
+        raise TceError(f"{what} failed ({status}): {msg}")

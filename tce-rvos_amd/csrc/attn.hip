@@ -1,0 +1,287 @@
+// Attention cores (head_dim 32, fp32).  Token counts on this path are small (49-token windows, <= 1 200
+// reduced tokens, 8..40 frame tokens, 32 text tokens), the work is <1 % of the clip's FLOPs, so these are
+// latency/LDS-oriented VALU kernels: one query row per lane (q and the output row live in registers), K/V
+// tiles staged in LDS and read back as wave-uniform (broadcast) ds_read_b128, scores of a whole tile kept
+// in registers so softmax needs one rescale per tile and no cross-lane traffic.
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+constexpr int HD = 32;  // head dim
+
+// ---------------------------------------------------------------------------------------------------
+// Swin window attention.  One wavefront per (frame, window, head); lanes 0..48 own the 49 query tokens.
+// The zero-padding to a multiple of 7, the cyclic shift, window partition/reverse and the final crop are
+// pure index arithmetic here (no torch.roll / F.pad / window_partition copies).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) window_attn_kernel(const float* __restrict__ qkv,
+                                                          const float* __restrict__ qkv_bias,
+                                                          const float* __restrict__ table, float* __restrict__ out,
+                                                          int T, int H, int W, int C, int nH, int shift, int nWy,
+                                                          int nWx, long long total) {
+  constexpr int WS = 7, NT = 49;
+  __shared__ __attribute__((aligned(16))) float sK[4][NT * HD];
+  __shared__ __attribute__((aligned(16))) float sV[4][NT * HD];
+  __shared__ float sB[4][169];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long item = (long long)blockIdx.x * 4 + wave;  // ((t*nWy + wy)*nWx + wx)*nH + h
+  const bool active = item < total;
+  const int Hp = nWy * WS, Wp = nWx * WS;
+  int h = 0, wx = 0, wy = 0, t = 0;
+  if (active) {
+    long long r = item;
+    h = (int)(r % nH); r /= nH;
+    wx = (int)(r % nWx); r /= nWx;
+    wy = (int)(r % nWy); r /= nWy;
+    t = (int)r;
+  }
+  const int C3 = 3 * C;
+  if (active) {
+    // stage K and V of the window's 49 tokens (padded tokens: the qkv bias), and this head's bias column
+    for (int i = lane; i < NT * 8; i += 64) {
+      const int j = i >> 3, d4 = i & 7;
+      const int yy = wy * WS + j / WS, xx = wx * WS + j % WS;      // shifted-frame coordinates
+      int ys = yy + shift, xs = xx + shift;                        // source (un-shifted, padded) coordinates
+      if (ys >= Hp) ys -= Hp;
+      if (xs >= Wp) xs -= Wp;
+      f32x4 kv, vv;
+      if (ys < H && xs < W) {
+        const float* p = qkv + (((long long)t * H + ys) * W + xs) * C3 + h * HD + d4 * 4;
+        kv = *reinterpret_cast<const f32x4*>(p + C);
+        vv = *reinterpret_cast<const f32x4*>(p + 2 * C);
+      } else {
+        kv = *reinterpret_cast<const f32x4*>(qkv_bias + C + h * HD + d4 * 4);
+        vv = *reinterpret_cast<const f32x4*>(qkv_bias + 2 * C + h * HD + d4 * 4);
+      }
+      *reinterpret_cast<f32x4*>(&sK[wave][j * HD + d4 * 4]) = kv;
+      *reinterpret_cast<f32x4*>(&sV[wave][j * HD + d4 * 4]) = vv;
+    }
+    for (int i = lane; i < 169; i += 64) sB[wave][i] = table[i * nH + h];
+  }
+  __syncthreads();
+  if (!active || lane >= NT) return;
+
+  const int iy = lane / WS, ix = lane % WS;
+  const int yy = wy * WS + iy, xx = wx * WS + ix;
+  int ys = yy + shift, xs = xx + shift;
+  if (ys >= Hp) ys -= Hp;
+  if (xs >= Wp) xs -= Wp;
+  const bool real = (ys < H && xs < W);
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  float q[HD];
+  {
+    const float* p = real ? qkv + (((long long)t * H + ys) * W + xs) * C3 + h * HD : qkv_bias + h * HD;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[d4 * 4 + j] = v[j] * scale;
+    }
+  }
+  // region id of the -100 shift mask (built on the padded, shifted grid)
+  int rid = 0;
+  if (shift > 0) {
+    const int ry = yy < Hp - WS ? 0 : (yy < Hp - shift ? 1 : 2);
+    const int rx = xx < Wp - WS ? 0 : (xx < Wp - shift ? 1 : 2);
+    rid = ry * 3 + rx;
+  }
+  float s[NT];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const f32x4* kp = reinterpret_cast<const f32x4*>(&sK[wave][j * HD]);
+    float a = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 kv = kp[d4];
+      a = fmaf(q[d4 * 4 + 0], kv[0], a);
+      a = fmaf(q[d4 * 4 + 1], kv[1], a);
+      a = fmaf(q[d4 * 4 + 2], kv[2], a);
+      a = fmaf(q[d4 * 4 + 3], kv[3], a);
+    }
+    const int jy = j / WS, jx = j % WS;
+    a += sB[wave][(iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1)];
+    if (shift > 0) {
+      const int y2 = wy * WS + jy, x2 = wx * WS + jx;
+      const int ry = y2 < Hp - WS ? 0 : (y2 < Hp - shift ? 1 : 2);
+      const int rx = x2 < Wp - WS ? 0 : (x2 < Wp - shift ? 1 : 2);
+      if (ry * 3 + rx != rid) a += -100.0f;
+    }
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    s[j] = __expf(s[j] - mx);
+    l += s[j];
+  }
+  const float inv = 1.0f / l;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const f32x4* vp = reinterpret_cast<const f32x4*>(&sV[wave][j * HD]);
+    const float pj = s[j] * inv;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 vv = vp[d4];
+      o[d4 * 4 + 0] = fmaf(pj, vv[0], o[d4 * 4 + 0]);
+      o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
+      o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]);
+      o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
+    }
+  }
+  if (real) {
+    float* po = out + (((long long)t * H + ys) * W + xs) * C + h * HD;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      f32x4 v = {o[d4 * 4], o[d4 * 4 + 1], o[d4 * 4 + 2], o[d4 * 4 + 3]};
+      *reinterpret_cast<f32x4*>(po + d4 * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic multi-head attention, flash-style with KT-key tiles.  Workgroup = NW wavefronts = 64*NW queries of
+// one (batch, head); the K/V tile (KT x 32 floats each) is staged once per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ V, float* __restrict__ O, int nheads,
+                                                  int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
+                                                  long long sK, long long sV, long long sO,
+                                                  const uint8_t* __restrict__ kmask, float scale) {
+  __shared__ __attribute__((aligned(16))) float sK_[KT * HD];
+  __shared__ __attribute__((aligned(16))) float sV_[KT * HD];
+  __shared__ float sM[KT];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int bh = blockIdx.y;
+  const int b = bh / nheads, h = bh - b * nheads;
+  const int qi = blockIdx.x * nthr + tid;
+  const bool qok = qi < Lq;
+  const float* Qb = Q + b * sQ + h * HD;
+  const float* Kb = K + b * sK + h * HD;
+  const float* Vb = V + b * sV + h * HD;
+  float q[HD], o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  if (qok) {
+    const float* p = Qb + (long long)qi * ldq;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[d4 * 4 + j] = v[j] * scale;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] = 0.f;
+  }
+  float m = -3.0e38f, l = 0.f;
+  for (int k0 = 0; k0 < Lk; k0 += KT) {
+    const int kn = min(KT, Lk - k0);
+    __syncthreads();
+    for (int i = tid; i < KT * 8; i += nthr) {
+      const int j = i >> 3, d4 = i & 7;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (j < kn) {
+        kv = *reinterpret_cast<const f32x4*>(Kb + (long long)(k0 + j) * ldk + d4 * 4);
+        vv = *reinterpret_cast<const f32x4*>(Vb + (long long)(k0 + j) * ldv + d4 * 4);
+      }
+      *reinterpret_cast<f32x4*>(&sK_[j * HD + d4 * 4]) = kv;
+      *reinterpret_cast<f32x4*>(&sV_[j * HD + d4 * 4]) = vv;
+    }
+    for (int j = tid; j < KT; j += nthr)
+      sM[j] = (j < kn && !(kmask && kmask[(long long)b * Lk + k0 + j])) ? 0.f : -3.0e38f;
+    __syncthreads();
+    float s[KT];
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const f32x4* kp = reinterpret_cast<const f32x4*>(&sK_[j * HD]);
+      float a = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < 8; ++d4) {
+        const f32x4 kv = kp[d4];
+        a = fmaf(q[d4 * 4 + 0], kv[0], a);
+        a = fmaf(q[d4 * 4 + 1], kv[1], a);
+        a = fmaf(q[d4 * 4 + 2], kv[2], a);
+        a = fmaf(q[d4 * 4 + 3], kv[3], a);
+      }
+      a = fminf(a, 3.0e38f) + sM[j];  // masked / absent keys -> -3e38
+      s[j] = a;
+      tmax = fmaxf(tmax, a);
+    }
+    const float mnew = fmaxf(m, tmax);
+    const float corr = __expf(m - mnew);
+    l *= corr;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] *= corr;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const float pj = (s[j] > -1.0e38f) ? __expf(s[j] - mnew) : 0.f;
+      l += pj;
+      const f32x4* vp = reinterpret_cast<const f32x4*>(&sV_[j * HD]);
+#pragma unroll
+      for (int d4 = 0; d4 < 8; ++d4) {
+        const f32x4 vv = vp[d4];
+        o[d4 * 4 + 0] = fmaf(pj, vv[0], o[d4 * 4 + 0]);
+        o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
+        o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]);
+        o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
+      }
+    }
+    m = mnew;
+  }
+  if (qok) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float* po = O + b * sO + (long long)qi * ldo + h * HD;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      f32x4 v = {o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(po + d4 * 4) = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
+                                   int32_t T, int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shift,
+                                   tceStream stream) {
+  TCE_CHECK_ARG(qkv && qkv_bias && bias_table && out, "tce_window_attn_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && nH > 0 && C == nH * 32, "tce_window_attn_f32: need C == nH*32 (C=%d nH=%d)", C,
+                nH);
+  TCE_CHECK_ARG(shift == 0 || shift == 3, "tce_window_attn_f32: shift must be 0 or 3 (window 7)");
+  TCE_CHECK_ARG(tce_aligned16(qkv) && tce_aligned16(qkv_bias) && tce_aligned16(out),
+                "tce_window_attn_f32: pointers must be 16-byte aligned");
+  const int nWy = (H + 6) / 7, nWx = (W + 6) / 7;
+  const long long total = (long long)T * nWy * nWx * nH;
+  hipLaunchKernelGGL(window_attn_kernel, dim3(tce_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
+                     bias_table, out, T, H, W, C, nH, shift, nWy, nWx, total);
+  TCE_CHECK_LAUNCH("tce_window_attn_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float* O, int32_t batch, int32_t nheads,
+                           int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int64_t sQ,
+                           int64_t sK, int64_t sV, int64_t sO, const uint8_t* kmask, float scale, tceStream stream) {
+  TCE_CHECK_ARG(Q && K && V && O, "tce_mha_f32: null pointer");
+  TCE_CHECK_ARG(batch > 0 && nheads > 0 && Lq > 0 && Lk > 0, "tce_mha_f32: bad sizes");
+  TCE_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && sQ % 4 == 0 && sK % 4 == 0 &&
+                    sV % 4 == 0 && sO % 4 == 0,
+                "tce_mha_f32: leading dims / strides must be multiples of 4");
+  TCE_CHECK_ARG(tce_aligned16(Q) && tce_aligned16(K) && tce_aligned16(V) && tce_aligned16(O),
+                "tce_mha_f32: pointers must be 16-byte aligned");
+  // few queries -> single-wave workgroups for more parallelism
+  const long long blocks256 = (long long)tce_cdiv(Lq, 256) * batch * nheads;
+  const int nthr = (blocks256 >= 512) ? 256 : 64;
+  dim3 grid(tce_cdiv(Lq, nthr), batch * nheads);
+  hipLaunchKernelGGL((mha_kernel<32>), grid, dim3(nthr), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
+                     ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
+  TCE_CHECK_LAUNCH("tce_mha_f32");
+  return TCE_OK;
+}

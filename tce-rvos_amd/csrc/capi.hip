@@ -1,0 +1,59 @@
+// ABI housekeeping: version, last-error string, hipGraph capture helpers.
+#include <stdarg.h>
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+static thread_local char g_err[512] = "";
+
+void tce_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int tce_abi_version(void) { return 1; }
+extern "C" const char* tce_last_error(void) { return g_err; }
+
+extern "C" int tce_graph_begin(tceStream stream) {
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    tce_set_error("tce_graph_begin: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  return TCE_OK;
+}
+
+extern "C" int tce_graph_end(tceStream stream, void** graph_exec_out) {
+  TCE_CHECK_ARG(graph_exec_out != nullptr, "tce_graph_end: null output");
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+  if (e != hipSuccess || graph == nullptr) {
+    tce_set_error("tce_graph_end: capture failed: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    tce_set_error("tce_graph_end: instantiate failed: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  *graph_exec_out = (void*)exec;
+  return TCE_OK;
+}
+
+extern "C" int tce_graph_launch(void* graph_exec, tceStream stream) {
+  TCE_CHECK_ARG(graph_exec != nullptr, "tce_graph_launch: null graph");
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    tce_set_error("tce_graph_launch: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  return TCE_OK;
+}
+
+extern "C" int tce_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return TCE_OK;
+}

@@ -1,0 +1,238 @@
+// fp32 GEMM / implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   C[M,N] = epi((A (+A2)) @ W^T + bias)      A [M,K] row-major, W [N,K] row-major (nn.Linear layout)
+//
+// Structure (one workgroup = 256 threads = 4 waves in a 2x2 grid over a BM x BN output tile):
+//   * K is walked in BK = 16 slices.  Each thread stages float4 pieces of the A and W tiles global -> VGPR
+//     (next slice prefetched while the current one is multiplied) -> LDS, stored K-MAJOR ([k][m], [k][n])
+//     so that one MFMA operand fetch is 32 consecutive floats per half-wave (conflict-free ds_read_b32):
+//     lane l supplies A[m = l&31][k = l>>5] and B[k = l>>5][n = l&31].
+//   * two LDS buffers, one barrier per K slice.
+//   * accumulators: (BM/64) x (BN/64) tiles of 32x32 per wave (f32x16 each); C/D map col = lane&31,
+//     row = (r&3) + 8*(r>>2) + 4*(lane>>5): the N index is on the lanes, so every store is a 128-byte row piece.
+//   * epilogue fused: bias, ReLU / GELU(erf), residual add or multiply.
+//   * CONV: the A loader computes the source pixel of each output row for the current (ky,kx) tap
+//     (zero outside the image) -- no im2col buffer.
+//   * tile ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
+// fp32 MFMA issues at the f32 vector rate (157 TFLOP/s peak); it is bit-exact f32 fmaf accumulation in k order.
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int BM, int BN, bool CONV>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
+  constexpr int LDAS = BM + 4;
+  constexpr int LDBS = BN + 4;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NA = BM / 64;  // float4 per thread for the A tile
+  constexpr int NB = BN / 64;
+  __shared__ float smem[2 * BK * (LDAS + LDBS)];
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BK * LDAS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int bz = blockIdx.z;
+
+  const float* __restrict__ A = p.A + (long long)bz * p.sA;
+  const float* __restrict__ A2 = p.A2 ? p.A2 + (long long)bz * p.sA2 : nullptr;
+  const float* __restrict__ W = p.W + (long long)bz * p.sW;
+  const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
+  const float* __restrict__ res = p.res ? p.res + (long long)bz * p.sRes : nullptr;
+  float* __restrict__ C = p.C + (long long)bz * p.sC;
+
+  const int kq = tid & 3;      // which float4 of the 16-wide K slice
+  const int lrow = tid >> 2;   // 0..63
+  // --- per-thread row bookkeeping for the A loader
+  long long a_off[NA];
+  bool a_ok[NA];
+  int c_t[NA], c_y[NA], c_x[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int gm = tm * BM + lrow + 64 * i;
+    a_ok[i] = gm < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int t = gm / hw, rem = gm - t * hw;
+      c_t[i] = t;
+      c_y[i] = (rem / p.Wo) * p.stride - p.pad;
+      c_x[i] = (rem % p.Wo) * p.stride - p.pad;
+      a_off[i] = 0;
+    } else {
+      a_off[i] = (long long)gm * p.lda;
+      c_t[i] = c_y[i] = c_x[i] = 0;
+    }
+  }
+  long long w_off[NB];
+  bool w_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int gn = tn * BN + lrow + 64 * i;
+    w_ok[i] = gn < p.N;
+    w_off[i] = (long long)gn * p.ldw;
+  }
+
+  f32x4 ra[NA], rb[NB];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (CONV) {
+        const int tap = (kt * BK) / p.Cin;
+        const int c0 = k0 - tap * p.Cin;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const int yi = c_y[i] + ky, xi = c_x[i] + kx;
+        if (a_ok[i] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd) {
+          v = *reinterpret_cast<const f32x4*>(A + (((long long)c_t[i] * p.H + yi) * p.Wd + xi) * p.Cin + c0);
+        }
+      } else {
+        if (a_ok[i]) {
+          v = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
+          if (A2) {
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(A2 + (long long)(tm * BM + lrow + 64 * i) * p.lda2 + k0);
+            v += v2;
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (w_ok[i]) v = *reinterpret_cast<const f32x4*>(W + w_off[i] + k0);
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* As = As0 + buf * BK * LDAS;
+    float* Bs = Bs0 + buf * BK * LDBS;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = lrow + 64 * i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * LDAS + m] = ra[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = lrow + 64 * i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDBS + n] = rb[i][j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* As = As0 + buf * BK * LDAS + wm * WM + l31;
+    const float* Bs = Bs0 + buf * BK * LDBS + wn * WN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + lhi;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[k * LDAS + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDBS + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = tn * BN + wn * WN + j * 32 + l31;
+    if (col >= p.N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (p.res_mode == 1) v += res[(long long)row * p.ldres + col];
+        else if (p.res_mode == 2) v *= res[(long long)row * p.ldres + col];
+        C[(long long)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+int launch(const tceGemmArgs& a, hipStream_t s) {
+  const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
+  dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
+  if (a.conv)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true>), grid, dim3(256), 0, s, a, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false>), grid, dim3(256), 0, s, a, tiles_m, tiles_n);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
+  TCE_CHECK_ARG(args != nullptr, "tce_gemm_f32: null args");
+  tceGemmArgs a = *args;
+  TCE_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "tce_gemm_f32: M,N,K must be positive (got %d,%d,%d)", a.M, a.N, a.K);
+  TCE_CHECK_ARG(a.K % BK == 0, "tce_gemm_f32: K=%d must be a multiple of %d", a.K, BK);
+  TCE_CHECK_ARG(a.A && a.W && a.C, "tce_gemm_f32: null A/W/C");
+  TCE_CHECK_ARG(tce_aligned16(a.A) && tce_aligned16(a.W) && (!a.A2 || tce_aligned16(a.A2)),
+                "tce_gemm_f32: A/A2/W must be 16-byte aligned");
+  TCE_CHECK_ARG(a.ldw % 4 == 0 && a.ldw >= a.K, "tce_gemm_f32: ldw=%d must be >= K and a multiple of 4", a.ldw);
+  TCE_CHECK_ARG(a.ldc >= a.N, "tce_gemm_f32: ldc=%d < N=%d", a.ldc, a.N);
+  TCE_CHECK_ARG(a.res_mode == 0 || (a.res && a.ldres >= a.N), "tce_gemm_f32: res_mode set but res/ldres invalid");
+  TCE_CHECK_ARG(a.act >= 0 && a.act <= 2 && a.res_mode >= 0 && a.res_mode <= 2, "tce_gemm_f32: bad act/res_mode");
+  if (a.batch <= 0) a.batch = 1;
+  if (a.conv) {
+    TCE_CHECK_ARG(a.A2 == nullptr, "tce_gemm_f32: A2 is not supported with conv");
+    TCE_CHECK_ARG(a.Cin % BK == 0, "tce_gemm_f32: conv Cin=%d must be a multiple of %d", a.Cin, BK);
+    TCE_CHECK_ARG(a.K == a.kh * a.kw * a.Cin, "tce_gemm_f32: conv K=%d != kh*kw*Cin", a.K);
+    TCE_CHECK_ARG(a.M == a.T * a.Ho * a.Wo, "tce_gemm_f32: conv M=%d != T*Ho*Wo", a.M);
+    TCE_CHECK_ARG(a.Ho == (a.H + 2 * a.pad - a.kh) / a.stride + 1 && a.Wo == (a.Wd + 2 * a.pad - a.kw) / a.stride + 1,
+                  "tce_gemm_f32: conv output size mismatch");
+  } else {
+    TCE_CHECK_ARG(a.lda % 4 == 0 && a.lda >= a.K, "tce_gemm_f32: lda=%d must be >= K and a multiple of 4", a.lda);
+    TCE_CHECK_ARG(!a.A2 || (a.lda2 % 4 == 0 && a.lda2 >= a.K), "tce_gemm_f32: lda2 invalid");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
+  // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
+  const long long b = a.batch;
+  const long long n128 = (long long)tce_cdiv(a.M, 128) * tce_cdiv(a.N, 128) * b;
+  const long long n12864 = (long long)tce_cdiv(a.M, 128) * tce_cdiv(a.N, 64) * b;
+  if (n128 >= 512 && a.N > 64) launch<128, 128>(a, s);
+  else if (n12864 >= 384 && a.M > 64) launch<128, 64>(a, s);
+  else launch<64, 64>(a, s);
+  TCE_CHECK_LAUNCH("tce_gemm_f32");
+  return TCE_OK;
+}

@@ -1,0 +1,256 @@
+// Small HBM-bound kernels: sine position maps, nearest / bilinear resampling on channels-last maps,
+// elementwise helpers of the decoder, and the dynamic mask head's pack + tail stages.
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+// position_encoding.py:64-84 for an all-valid mask: y_embed = (y+1-0.5)/(h+1e-6)*2pi, channels [pos_y(F) | pos_x(F)],
+// channel i: embed / 10000^(2*(i/2)/F), sin for even i, cos for odd i.
+__global__ void __launch_bounds__(256) pos_sine2d_kernel(float* __restrict__ out, const float* __restrict__ add, int T,
+                                                         int h, int w, int F, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int C = 2 * F;
+  const int c = (int)(idx % C);
+  const long long tok = idx / C;
+  const int x = (int)(tok % w);
+  const int y = (int)((tok / w) % h);
+  const float two_pi = 6.283185307179586f;
+  const bool is_y = c < F;
+  const int i = is_y ? c : c - F;
+  const float e = is_y ? ((float)(y + 1) - 0.5f) / ((float)h + 1e-6f) * two_pi
+                       : ((float)(x + 1) - 0.5f) / ((float)w + 1e-6f) * two_pi;
+  const float dim_t = powf(10000.0f, (float)(2 * (i / 2)) / (float)F);
+  const float v = e / dim_t;
+  float r = (i & 1) ? cosf(v) : sinf(v);
+  if (add) r += add[c];
+  out[idx] = r;
+}
+
+__global__ void __launch_bounds__(256) resize_nearest_kernel(const float* __restrict__ in, const float* __restrict__ add,
+                                                             float* __restrict__ out, int T, int h, int w, int ho,
+                                                             int wo, int C4, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4);
+  long long r = idx / C4;
+  const int xo = (int)(r % wo); r /= wo;
+  const int yo = (int)(r % ho);
+  const int t = (int)(r / ho);
+  const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+  const int yi = min((int)floorf((float)yo * sy), h - 1);
+  const int xi = min((int)floorf((float)xo * sx), w - 1);
+  f32x4 v = reinterpret_cast<const f32x4*>(in)[(((long long)t * h + yi) * w + xi) * C4 + c];
+  if (add) v += reinterpret_cast<const f32x4*>(add)[idx];
+  reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in,
+                                                              const float* __restrict__ add, float* __restrict__ out,
+                                                              int T, int h, int w, int ho, int wo, int C4,
+                                                              long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4);
+  long long r = idx / C4;
+  const int xo = (int)(r % wo); r /= wo;
+  const int yo = (int)(r % ho);
+  const int t = (int)(r / ho);
+  const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+  const float fy = fmaxf(sy * ((float)yo + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(sx * ((float)xo + 0.5f) - 0.5f, 0.f);
+  const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const f32x4* i4 = reinterpret_cast<const f32x4*>(in) + (long long)t * h * w * C4 + c;
+  const f32x4 v00 = i4[((long long)y0 * w + x0) * C4], v01 = i4[((long long)y0 * w + x1) * C4];
+  const f32x4 v10 = i4[((long long)y1 * w + x0) * C4], v11 = i4[((long long)y1 * w + x1) * C4];
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+  if (add) o += reinterpret_cast<const f32x4*>(add)[idx];
+  reinterpret_cast<f32x4*>(out)[idx] = o;
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long long n, long long nb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i % nb];
+}
+
+__global__ void __launch_bounds__(256) sigmoid_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                      long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, 1e-5f), x2 = fmaxf(1.f - x, 1e-5f);
+  return logf(x1 / x2);
+}
+
+__global__ void __launch_bounds__(256) box_refine_kernel(const float* __restrict__ tmp, const float* __restrict__ ref,
+                                                         float* __restrict__ out, int n, int ref_dim) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 4) return;
+  const int r = i >> 2, c = i & 3;
+  float v = tmp[i];
+  if (c < ref_dim) v += inv_sigmoid(ref[r * ref_dim + c]);
+  out[i] = 1.f / (1.f + expf(-v));
+}
+
+// ---- dynamic mask head -------------------------------------------------------------------------------
+constexpr int DC = 8;        // dynamic_mask_channels
+constexpr int TAIL_LD = 112;  // floats per (level, frame, query) in the packed tail parameter block
+
+__global__ void __launch_bounds__(256) mask_pack_kernel(const float* __restrict__ params, float* __restrict__ w0f,
+                                                        float* __restrict__ tail, int nl, int T, int Q, int Cm) {
+  // one workgroup per (level, frame, query)
+  const int item = blockIdx.x;  // (lvl*T + t)*Q + q
+  const int q = item % Q, t = (item / Q) % T, lvl = item / (Q * T);
+  const int npar = DC * (Cm + 2) + DC * DC + DC + DC + DC + 1;
+  const float* p = params + ((long long)lvl * T * Q + t * Q + q) * npar;
+  float* wrow = w0f + ((long long)t * (nl * Q * DC) + (lvl * Q + q) * DC) * Cm;
+  for (int i = threadIdx.x; i < DC * Cm; i += 256) {
+    const int c = i / Cm, k = i - c * Cm;
+    wrow[(long long)c * Cm + k] = p[c * (Cm + 2) + k];
+  }
+  float* tl = tail + ((long long)lvl * T * Q + t * Q + q) * TAIL_LD;
+  const int off1 = DC * (Cm + 2), off2 = off1 + DC * DC, off3 = off2 + DC;
+  for (int i = threadIdx.x; i < TAIL_LD; i += 256) {
+    float v = 0.f;
+    if (i < 8) v = p[i * (Cm + 2) + Cm];                  // w0 x-coordinate column
+    else if (i < 16) v = p[(i - 8) * (Cm + 2) + Cm + 1];  // w0 y-coordinate column
+    else if (i < 24) v = p[off3 + (i - 16)];              // b0
+    else if (i < 88) v = p[off1 + (i - 24)];              // w1 [out][in]
+    else if (i < 96) v = p[off3 + 8 + (i - 88)];          // b1
+    else if (i < 104) v = p[off2 + (i - 96)];             // w2
+    else if (i == 104) v = p[off3 + 16];                  // b2
+    tl[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) mask_tail_kernel(const float* __restrict__ G, const float* __restrict__ tail,
+                                                        const float* __restrict__ refs, int ref_ld,
+                                                        float* __restrict__ masks, int nl, int T, int Q, int h, int w,
+                                                        float img_h, float img_w, int stride_px) {
+  __shared__ float sp[TAIL_LD];
+  __shared__ float sref[2];
+  const int item = blockIdx.y;  // (lvl*T + t)*Q + q
+  const int q = item % Q, t = (item / Q) % T, lvl = item / (Q * T);
+  const float* tl = tail + ((long long)lvl * T * Q + t * Q + q) * TAIL_LD;
+  if (threadIdx.x < TAIL_LD) sp[threadIdx.x] = tl[threadIdx.x];
+  if (threadIdx.x < 2) sref[threadIdx.x] = refs[((long long)lvl * T * Q + t * Q + q) * ref_ld + threadIdx.x];
+  __syncthreads();
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int hw = h * w;
+  if (pix >= hw) return;
+  const int y = pix / w, x = pix - y * w;
+  const int ncol = nl * Q * DC;
+  const float* g = G + ((long long)t * hw + pix) * ncol + (lvl * Q + q) * DC;
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
+  const float relx = sref[0] * img_w - (float)(x * stride_px + stride_px / 2);
+  const float rely = sref[1] * img_h - (float)(y * stride_px + stride_px / 2);
+  float h0[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) {
+    const float gv = c < 4 ? g0[c] : g1[c - 4];
+    h0[c] = fmaxf(gv + sp[c] * relx + sp[8 + c] * rely + sp[16 + c], 0.f);
+  }
+  float o = sp[104];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) {
+    float a = sp[88 + c];
+#pragma unroll
+    for (int k = 0; k < DC; ++k) a = fmaf(sp[24 + c * DC + k], h0[k], a);
+    o = fmaf(sp[96 + c], fmaxf(a, 0.f), o);
+  }
+  masks[((long long)item) * hw + pix] = o;
+}
+
+}  // namespace
+
+extern "C" int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F,
+                                  tceStream stream) {
+  TCE_CHECK_ARG(out && T > 0 && h > 0 && w > 0 && F > 0, "tce_pos_sine2d_f32: bad arguments");
+  const long long total = (long long)T * h * w * 2 * F;
+  hipLaunchKernelGGL(pos_sine2d_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, add, T, h, w,
+                     F, total);
+  TCE_CHECK_LAUNCH("tce_pos_sine2d_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_resize_nearest_f32(const float* in, const float* add, float* out, int32_t T, int32_t h, int32_t w,
+                                      int32_t ho, int32_t wo, int32_t C, tceStream stream) {
+  TCE_CHECK_ARG(in && out && T > 0 && h > 0 && w > 0 && ho > 0 && wo > 0 && C > 0 && C % 4 == 0,
+                "tce_resize_nearest_f32: bad arguments");
+  TCE_CHECK_ARG(tce_aligned16(in) && tce_aligned16(out) && (!add || tce_aligned16(add)),
+                "tce_resize_nearest_f32: pointers must be 16-byte aligned");
+  const long long total = (long long)T * ho * wo * (C / 4);
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, add, out,
+                     T, h, w, ho, wo, C / 4, total);
+  TCE_CHECK_LAUNCH("tce_resize_nearest_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_resize_bilinear_f32(const float* in, const float* add, float* out, int32_t T, int32_t h, int32_t w,
+                                       int32_t ho, int32_t wo, int32_t C, tceStream stream) {
+  TCE_CHECK_ARG(in && out && T > 0 && h > 0 && w > 0 && ho > 0 && wo > 0 && C > 0 && C % 4 == 0,
+                "tce_resize_bilinear_f32: bad arguments");
+  TCE_CHECK_ARG(tce_aligned16(in) && tce_aligned16(out) && (!add || tce_aligned16(add)),
+                "tce_resize_bilinear_f32: pointers must be 16-byte aligned");
+  const long long total = (long long)T * ho * wo * (C / 4);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, add,
+                     out, T, h, w, ho, wo, C / 4, total);
+  TCE_CHECK_LAUNCH("tce_resize_bilinear_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t nb, tceStream stream) {
+  TCE_CHECK_ARG(a && b && out && n > 0 && nb > 0, "tce_add_f32: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(tce_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n,
+                     (long long)nb);
+  TCE_CHECK_LAUNCH("tce_add_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_sigmoid_f32(const float* x, float* out, int64_t n, tceStream stream) {
+  TCE_CHECK_ARG(x && out && n > 0, "tce_sigmoid_f32: bad arguments");
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(tce_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n);
+  TCE_CHECK_LAUNCH("tce_sigmoid_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_box_refine_f32(const float* tmp, const float* ref, float* out, int32_t n, int32_t ref_dim,
+                                  tceStream stream) {
+  TCE_CHECK_ARG(tmp && ref && out && n > 0 && (ref_dim == 2 || ref_dim == 4), "tce_box_refine_f32: bad arguments");
+  hipLaunchKernelGGL(box_refine_kernel, dim3(tce_cdiv(n * 4, 256)), dim3(256), 0, (hipStream_t)stream, tmp, ref, out, n,
+                     ref_dim);
+  TCE_CHECK_LAUNCH("tce_box_refine_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_mask_pack_f32(const float* params, float* w0f, float* tail, int32_t nl, int32_t T, int32_t Q,
+                                 int32_t Cm, tceStream stream) {
+  TCE_CHECK_ARG(params && w0f && tail && nl > 0 && T > 0 && Q > 0 && Cm > 0 && Cm % 16 == 0,
+                "tce_mask_pack_f32: bad arguments");
+  hipLaunchKernelGGL(mask_pack_kernel, dim3(nl * T * Q), dim3(256), 0, (hipStream_t)stream, params, w0f, tail, nl, T, Q,
+                     Cm);
+  TCE_CHECK_LAUNCH("tce_mask_pack_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_mask_tail_f32(const float* G, const float* tail, const float* refs, int32_t ref_ld, float* masks,
+                                 int32_t nl, int32_t T, int32_t Q, int32_t h, int32_t w, float img_h, float img_w,
+                                 int32_t stride_px, tceStream stream) {
+  TCE_CHECK_ARG(G && tail && refs && masks && nl > 0 && T > 0 && Q > 0 && h > 0 && w > 0 && ref_ld >= 2,
+                "tce_mask_tail_f32: bad arguments");
+  TCE_CHECK_ARG(tce_aligned16(G), "tce_mask_tail_f32: G must be 16-byte aligned");
+  hipLaunchKernelGGL(mask_tail_kernel, dim3(tce_cdiv(h * w, 256), nl * T * Q), dim3(256), 0, (hipStream_t)stream, G,
+                     tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px);
+  TCE_CHECK_LAUNCH("tce_mask_tail_f32");
+  return TCE_OK;
+}

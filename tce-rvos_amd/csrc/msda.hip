@@ -1,0 +1,210 @@
+// Multi-scale deformable attention forward (the reference's only native op) for gfx950.
+//
+// Work decomposition: one half-wavefront (32 lanes) per (frame n, query q, head m); lane = channel d of the
+// D = 32 wide head, so every bilinear corner fetch is one contiguous 128-byte row of value[N,S,M,D].
+// The L*P (<= 16) sampling points of the (q, m) pair are distributed one per lane for the location /
+// softmax arithmetic (wave shuffles for the max / sum), then broadcast lane-to-lane with ds_bpermute-free
+// __shfl while all 32 lanes gather.  Value rows are served by L2 / Infinity Cache (a frame's value tensor
+// is 4.9 MB at config 2).
+//
+// Boundary rule restated from ms_deform_im2col_cuda.cuh:34-85,438-446:
+//   h_im = y*H - 0.5, w_im = x*W - 0.5; the sample counts iff h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+//   each of the four corners is dropped individually when it falls outside the level.
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+constexpr int D = 32;
+constexpr int MAXL = 8;
+
+struct LevelInfo {
+  int H[MAXL], W[MAXL], start[MAXL];
+};
+
+__device__ __forceinline__ float bilinear_gather(const float* __restrict__ vbase, int Hl, int Wl, long long row_stride,
+                                                 float h_im, float w_im) {
+  // vbase points at value[n, level_start, m, d]; row_stride = M*D floats between consecutive spatial positions
+  float val = 0.f;
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    if (h_low >= 0 && w_low >= 0) v1 = vbase[((long long)h_low * Wl + w_low) * row_stride];
+    if (h_low >= 0 && w_high <= Wl - 1) v2 = vbase[((long long)h_low * Wl + w_high) * row_stride];
+    if (h_high <= Hl - 1 && w_low >= 0) v3 = vbase[((long long)h_high * Wl + w_low) * row_stride];
+    if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = vbase[((long long)h_high * Wl + w_high) * row_stride];
+    val = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
+  }
+  return val;
+}
+
+// FUSED = false: sampling_loc / attn_weight given (the reference op's signature)
+// FUSED = true : raw projection rows (offsets | logits) + reference points
+template <bool FUSED>
+__global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ value, const float* __restrict__ loc_or_proj,
+                                                   const float* __restrict__ aw_or_ref, float* __restrict__ out,
+                                                   LevelInfo lv, int N, int S, int M, int Lq, int L, int P,
+                                                   int ref_dim, int ref_per_frame, long long total) {
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, d = lane & 31;
+  const long long item = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;  // (n*Lq + q)*M + m
+  const bool active = item < total;
+  const int LP = L * P;
+  int m = 0, q = 0, n = 0;
+  if (active) {
+    long long r = item;
+    m = (int)(r % M); r /= M;
+    q = (int)(r % Lq);
+    n = (int)(r / Lq);
+  }
+  // lane j (< LP) of the half-wave computes point j's (x, y, weight)
+  const int pj = d;  // point index handled by this lane
+  float px = 0.f, py = 0.f, pw = 0.f;
+  if (active && pj < LP) {
+    const int l = pj / P;
+    if (FUSED) {
+      const int ncol = M * LP * 3;
+      const float* row = loc_or_proj + ((long long)n * Lq + q) * ncol;
+      const float ox = row[(m * LP + pj) * 2 + 0];
+      const float oy = row[(m * LP + pj) * 2 + 1];
+      pw = row[M * LP * 2 + m * LP + pj];  // logit
+      const float* rp = aw_or_ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+      if (ref_dim == 2) {
+        px = rp[0] + ox / (float)lv.W[l];
+        py = rp[1] + oy / (float)lv.H[l];
+      } else {
+        px = rp[0] + ox / (float)P * rp[2] * 0.5f;
+        py = rp[1] + oy / (float)P * rp[3] * 0.5f;
+      }
+    } else {
+      const long long base = (((long long)n * Lq + q) * M + m) * LP + pj;
+      px = loc_or_proj[base * 2 + 0];
+      py = loc_or_proj[base * 2 + 1];
+      pw = aw_or_ref[base];
+    }
+  }
+  if (FUSED) {
+    // softmax over the LP logits held by lanes 0..LP-1 of each half-wave (xor-shuffles stay inside 16 lanes)
+    float v = (active && pj < LP) ? pw : -3.0e38f;
+    float mx = v;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e = (active && pj < LP) ? __expf(v - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    pw = e / sum;
+  }
+  float acc = 0.f;
+  const long long row_stride = (long long)M * D;
+  const float* vn = value + ((long long)n * S) * row_stride + m * D + d;
+  for (int j = 0; j < LP; ++j) {
+    const int src = (half << 5) + j;
+    const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), w = __shfl(pw, src, 64);
+    const int l = j / P;
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+    if (active) acc += w * bilinear_gather(vn + (long long)lv.start[l] * row_stride, Hl, Wl, row_stride, h_im, w_im);
+  }
+  if (active) out[item * D + d] = acc;
+}
+
+__global__ void read_levels_kernel(const int64_t* shapes, const int64_t* starts, int L, int* out) {
+  const int i = threadIdx.x;
+  if (i < L) {
+    out[i] = (int)shapes[2 * i];
+    out[MAXL + i] = (int)shapes[2 * i + 1];
+    out[2 * MAXL + i] = (int)starts[i];
+  }
+}
+
+// variant of the plain kernel that reads level geometry from device memory (the reference op passes
+// spatial_shapes / level_start_index as device int64 tensors)
+__global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __restrict__ value,
+                                                             const int64_t* __restrict__ shapes,
+                                                             const int64_t* __restrict__ starts,
+                                                             const float* __restrict__ loc,
+                                                             const float* __restrict__ aw, float* __restrict__ out,
+                                                             int N, int S, int M, int Lq, int L, int P,
+                                                             long long total) {
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, d = lane & 31;
+  const long long item = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+  const bool active = item < total;
+  const int LP = L * P;
+  int m = 0, n = 0;
+  if (active) {
+    long long r = item;
+    m = (int)(r % M); r /= M;
+    n = (int)(r / Lq);
+  }
+  float px = 0.f, py = 0.f, pw = 0.f;
+  if (active && d < LP) {
+    const long long base = item * LP + d;
+    px = loc[base * 2 + 0];
+    py = loc[base * 2 + 1];
+    pw = aw[base];
+  }
+  float acc = 0.f;
+  const long long row_stride = (long long)M * D;
+  const float* vn = value + ((long long)n * S) * row_stride + m * D + d;
+  for (int j = 0; j < LP; ++j) {
+    const int src = (half << 5) + j;
+    const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), w = __shfl(pw, src, 64);
+    const int l = j / P;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const long long st = starts[l];
+    const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+    if (active) acc += w * bilinear_gather(vn + st * row_stride, Hl, Wl, row_stride, h_im, w_im);
+  }
+  if (active) out[item * D + d] = acc;
+}
+
+}  // namespace
+
+extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                              const int64_t* level_start_index, const float* sampling_loc,
+                                              const float* attn_weight, float* out, int32_t N, int32_t S, int32_t M,
+                                              int32_t Dh, int32_t Lq, int32_t L, int32_t P, tceStream stream) {
+  TCE_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                "tce_ms_deform_attn_forward_f32: null pointer");
+  TCE_CHECK_ARG(Dh == D, "tce_ms_deform_attn_forward_f32: head dim must be 32 (got %d)", Dh);
+  TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 32,
+                "tce_ms_deform_attn_forward_f32: bad sizes (L*P must be <= 32)");
+  const long long total = (long long)N * Lq * M;
+  hipLaunchKernelGGL(msda_plain_dev_kernel, dim3(tce_cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, value,
+                     spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
+  TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const float* ref, float* out,
+                                  const int32_t* shapes_hw, int32_t N, int32_t S, int32_t M, int32_t Lq, int32_t L,
+                                  int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream) {
+  TCE_CHECK_ARG(value && proj && ref && out && shapes_hw, "tce_msda_fused_f32: null pointer");
+  TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 16,
+                "tce_msda_fused_f32: bad sizes (L*P must be <= 16)");
+  TCE_CHECK_ARG(ref_dim == 2 || ref_dim == 4, "tce_msda_fused_f32: ref_dim must be 2 or 4");
+  LevelInfo lv;
+  int start = 0;
+  for (int l = 0; l < MAXL; ++l) {
+    if (l < L) {
+      lv.H[l] = shapes_hw[2 * l];
+      lv.W[l] = shapes_hw[2 * l + 1];
+      lv.start[l] = start;
+      start += lv.H[l] * lv.W[l];
+    } else {
+      lv.H[l] = lv.W[l] = 1;
+      lv.start[l] = 0;
+    }
+  }
+  TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
+  const long long total = (long long)N * Lq * M;
+  hipLaunchKernelGGL((msda_kernel<true>), dim3(tce_cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, value, proj, ref,
+                     out, lv, N, S, M, Lq, L, P, ref_dim, ref_per_frame, total);
+  TCE_CHECK_LAUNCH("tce_msda_fused_f32");
+  return TCE_OK;
+}

@@ -1,0 +1,339 @@
+// Row / group normalisations.  All HBM-bound: one read + one write of the activation, float4 accesses,
+// wavefront-shuffle reductions (64 lanes), statistics in fp32 two-pass form (mean, then centred variance)
+// to match PyTorch's numerics.
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per row, rows of C floats (C % 4 == 0).  The row is read from HBM once
+// (pass 1) and re-read from L1/L2 for the centred variance and the write.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out,
+                                                        long long M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * C);
+  const f32x4* rr = r ? reinterpret_cast<const f32x4*>(r + row * C) : nullptr;
+  const int n4 = C >> 2;
+  float s = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = xr[i];
+    if (rr) v += rr[i];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = xr[i];
+    if (rr) v += rr[i];
+    const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + row * C);
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = xr[i];
+    if (rr) v += rr[i];
+    const f32x4 g = g4[i], b = b4[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * g[j] + b[j];
+    o4[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PatchMerging front half: virtual row = concat of 4 neighbours (zero outside), LayerNorm(4C).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patch_merge_ln_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ out,
+                                                             int T, int H, int W, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)T * H2 * W2) return;
+  const int t = (int)(row / (H2 * W2));
+  const int rem = (int)(row - (long long)t * H2 * W2);
+  const int y2 = rem / W2, x2 = rem - y2 * W2;
+  // quadrant order of the reference: (dy,dx) = (0,0),(1,0),(0,1),(1,1)
+  const f32x4* src[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int yy = 2 * y2 + (qd & 1), xx = 2 * x2 + (qd >> 1);
+    src[qd] = (yy < H && xx < W) ? reinterpret_cast<const f32x4*>(x + (((long long)t * H + yy) * W + xx) * C) : nullptr;
+  }
+  const int c4 = C >> 2, n4 = C;  // 4C floats = C float4
+  float s = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    const int qd = i / c4, j = i - qd * c4;
+    if (src[qd]) {
+      const f32x4 v = src[qd][j];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)(4 * C);
+  float q = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    const int qd = i / c4, j = i - qd * c4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src[qd]) v = src[qd][j];
+    const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)(4 * C) + eps);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + row * 4 * C);
+  for (int i = lane; i < n4; i += 64) {
+    const int qd = i / c4, j = i - qd * c4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src[qd]) v = src[qd][j];
+    const f32x4 g = g4[i], b = b4[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (v[k] - mean) * rstd * g[k] + b[k];
+    o4[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PatchEmbed: 4x4 stride-4 conv of an NCHW frame (3 channels -> K = 48) + LayerNorm(C).
+// One wavefront per output token: the 48 input taps are wave-uniform (LDS broadcast), lane c computes
+// channels c, c+64, ...  Weights w [C,48] are read once per workgroup into LDS.
+// ---------------------------------------------------------------------------------------------------
+template <int MAXC_PER_LANE>
+__global__ void __launch_bounds__(256) patch_embed_kernel(const float* __restrict__ frames,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out,
+                                                          int T, int H, int W, int C, float eps, int tokens_per_block) {
+  extern __shared__ float sm[];
+  float* ws = sm;                 // [48][C]  (k-major so that lanes read consecutive channels)
+  float* taps = sm + 48 * C;      // [4 waves][48]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 48 * C; i += 256) {
+    const int c = i / 48, k = i - c * 48;
+    ws[k * C + c] = w[i];
+  }
+  __syncthreads();
+  const int Hp = (H + 3) >> 2, Wp = (W + 3) >> 2;
+  const long long ntok = (long long)T * Hp * Wp;
+  for (int it = 0; it < tokens_per_block; it += 4) {
+    const long long tok = (long long)blockIdx.x * tokens_per_block + it + wave;
+    if (tok < ntok) {
+      const int t = (int)(tok / (Hp * Wp));
+      const int rem = (int)(tok - (long long)t * Hp * Wp);
+      const int py = rem / Wp, px = rem - py * Wp;
+      if (lane < 48) {
+        const int c = lane >> 4, ky = (lane >> 2) & 3, kx = lane & 3;
+        const int yy = py * 4 + ky, xx = px * 4 + kx;
+        taps[wave * 48 + lane] = (yy < H && xx < W) ? frames[(((long long)t * 3 + c) * H + yy) * W + xx] : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (tok < ntok) {
+      float acc[MAXC_PER_LANE];
+#pragma unroll
+      for (int j = 0; j < MAXC_PER_LANE; ++j) {
+        const int c = lane + 64 * j;
+        acc[j] = (c < C) ? b[c] : 0.f;
+      }
+      for (int k = 0; k < 48; ++k) {
+        const float xv = taps[wave * 48 + k];
+#pragma unroll
+        for (int j = 0; j < MAXC_PER_LANE; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) acc[j] = fmaf(xv, ws[k * C + c], acc[j]);
+        }
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXC_PER_LANE; ++j)
+        if (lane + 64 * j < C) s += acc[j];
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXC_PER_LANE; ++j)
+        if (lane + 64 * j < C) {
+          const float d = acc[j] - mean;
+          q += d * d;
+        }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+      for (int j = 0; j < MAXC_PER_LANE; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) out[tok * C + c] = (acc[j] - mean) * rstd * gamma[c] + beta[c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm on channels-last [T, HW, C]: each (frame, group) is split over `nsplit` workgroups that
+// compute (count, mean, M2) of their row range (two passes over the chunk, second one from L2); the apply
+// kernel merges the partials with Chan's formula and normalises (+ReLU).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) groupnorm_stats_kernel(const float* __restrict__ x, float* __restrict__ ws,
+                                                              int HW, int C, int G, int nsplit) {
+  __shared__ float red[4];
+  const int tg = blockIdx.x;  // t*G + g
+  const int sp = blockIdx.y;
+  const int t = tg / G, g = tg - t * G;
+  const int cg = C / G;
+  const int rows_per = (HW + nsplit - 1) / nsplit;
+  const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
+  const float* base = x + (long long)t * HW * C + g * cg;
+  const int n = max(0, r1 - r0) * cg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const int rr = i / cg, c = i - rr * cg;
+    s += base[(long long)(r0 + rr) * C + c];
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = n > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (float)n : 0.f;
+  __syncthreads();
+  float q = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const int rr = i / cg, c = i - rr * cg;
+    const float d = base[(long long)(r0 + rr) * C + c] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  if (tid == 0) {
+    float* o = ws + ((long long)tg * nsplit + sp) * 3;
+    o[0] = (float)n;
+    o[1] = mean;
+    o[2] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ ws,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ out,
+                                                              int HW, int C, int G, int nsplit, float eps, int relu,
+                                                              int rows_per_block) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  float* scale = sm;
+  float* shift = sm + C;
+  const int t = blockIdx.y;
+  const int cg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    const float* p = ws + ((long long)(t * G + g) * nsplit) * 3;
+    float n = p[0], mean = p[1], m2 = p[2];
+    for (int i = 1; i < nsplit; ++i) {
+      const float nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
+      if (nb > 0.f) {
+        const float nt = n + nb, d = mb - mean;
+        mean += d * (nb / nt);
+        m2 += m2b + d * d * (n * nb / nt);
+        n = nt;
+      }
+    }
+    const float rstd = rsqrtf(m2 / n + eps);
+    const float sc = rstd * gamma[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+  }
+  __syncthreads();
+  const int c4 = C >> 2;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min((long long)HW, r0 + rows_per_block);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (long long)t * HW * C);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + (long long)t * HW * C);
+  const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
+  const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
+  for (long long i = r0 * c4 + threadIdx.x; i < r1 * c4; i += 256) {
+    const int c = (int)(i % c4);
+    const f32x4 v = x4[i], a = sc4[c], b = sh4[c];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = v[j] * a[j] + b[j];
+      if (relu) o[j] = fmaxf(o[j], 0.f);
+    }
+    o4[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, float* out,
+                                 int64_t M, int32_t C, float eps, tceStream stream) {
+  TCE_CHECK_ARG(x && gamma && beta && out, "tce_layernorm_f32: null pointer");
+  TCE_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "tce_layernorm_f32: need M>0, C%%4==0 (M=%lld C=%d)", (long long)M, C);
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta) &&
+                    (!r || tce_aligned16(r)),
+                "tce_layernorm_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, out,
+                     (long long)M, C, eps);
+  TCE_CHECK_LAUNCH("tce_layernorm_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_patch_merge_ln_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t T,
+                                      int32_t H, int32_t W, int32_t C, float eps, tceStream stream) {
+  TCE_CHECK_ARG(x && gamma && beta && out, "tce_patch_merge_ln_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "tce_patch_merge_ln_f32: bad shape");
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta),
+                "tce_patch_merge_ln_f32: pointers must be 16-byte aligned");
+  const long long rows = (long long)T * ((H + 1) / 2) * ((W + 1) / 2);
+  hipLaunchKernelGGL(patch_merge_ln_kernel, dim3(tce_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                     out, T, H, W, C, eps);
+  TCE_CHECK_LAUNCH("tce_patch_merge_ln_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const float* b, const float* gamma,
+                                   const float* beta, float* out, int32_t T, int32_t H, int32_t W, int32_t C, float eps,
+                                   tceStream stream) {
+  TCE_CHECK_ARG(frames && w && b && gamma && beta && out, "tce_patch_embed_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && C > 0 && C <= 256, "tce_patch_embed_f32: need 0 < C <= 256 (C=%d)", C);
+  const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
+  const long long ntok = (long long)T * Hp * Wp;
+  const int tpb = 64;
+  const size_t smem = (size_t)(48 * C + 4 * 48) * sizeof(float);
+  hipLaunchKernelGGL((patch_embed_kernel<4>), dim3(tce_cdiv(ntok, tpb)), dim3(256), smem, (hipStream_t)stream, frames, w,
+                     b, gamma, beta, out, T, H, W, C, eps, tpb);
+  TCE_CHECK_LAUNCH("tce_patch_embed_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_groupnorm_nsplit(int32_t HW) {
+  int n = HW / 512;
+  if (n < 1) n = 1;
+  if (n > 32) n = 32;
+  return n;
+}
+
+extern "C" int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
+                                 int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream) {
+  TCE_CHECK_ARG(x && gamma && beta && out && ws, "tce_groupnorm_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0, "tce_groupnorm_f32: bad shape");
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out), "tce_groupnorm_f32: x/out must be 16-byte aligned");
+  const int nsplit = tce_groupnorm_nsplit(HW);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(T * G, nsplit), dim3(256), 0, s, x, ws, HW, C, G, nsplit);
+  const int rows_per_block = 64;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(tce_cdiv(HW, rows_per_block), T), dim3(256),
+                     (size_t)2 * C * sizeof(float), s, x, ws, gamma, beta, out, HW, C, G, nsplit, eps, relu,
+                     rows_per_block);
+  TCE_CHECK_LAUNCH("tce_groupnorm_f32");
+  return TCE_OK;
+}

@@ -1,0 +1,301 @@
+"""Thin tensor plumbing over the C ABI (include/tce_rvos.h): torch owns device memory and streams, every
+arithmetic stage is a HIP kernel of libtce_rvos.so.  No op here has a PyTorch fallback."""
+import ctypes as C
+
+import torch
+
+from ._lib import GemmArgs, check, lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+RES_NONE, RES_ADD, RES_MUL = 0, 1, 2
+
+
+class Arena:
+    """Bump allocator over one device buffer with mark/release scoping.  A forward pass makes the same
+    sequence of requests every time, so addresses are stable across calls -- what hipGraph replay needs."""
+
+    ALIGN = 256
+
+    def __init__(self, device, nbytes):
+        self.device = torch.device(device)
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.off = 0
+        self.peak = 0
+
+    def reset(self):
+        self.off = 0
+
+    def mark(self):
+        return self.off
+
+    def release(self, mark):
+        self.off = mark
+
+    def alloc(self, *shape, dtype=torch.float32):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        end = start + nbytes
+        if end > self.buf.numel():
+            raise MemoryError(f"tce_rvos_amd arena exhausted: need {end} bytes, have {self.buf.numel()}")
+        self.off = end
+        self.peak = max(self.peak, end)
+        return self.buf[start:end].view(dtype).view(*[int(s) for s in shape])
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
+
+
+def _rows(t, name):
+    """2-D row view: returns (ptr, rows, cols, ld).  Accepts [..., C] contiguous or 2-D with row stride."""
+    _chk(t, name)
+    if t.dim() == 2 and t.stride(1) == 1:
+        return t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous or a 2-D row-strided view")
+    c = t.shape[-1]
+    return t.data_ptr(), t.numel() // c, c, c
+
+
+def gemm(a, w, bias=None, a2=None, act=ACT_NONE, res=None, res_mode=RES_NONE, out=None, alloc=None):
+    """out[M,N] = epi((a (+a2)) @ w.T + bias).  a [M,K] (row-strided ok), w [N,K]."""
+    ap, M, K, lda = _rows(a, "a")
+    wp, N, Kw, ldw = _rows(w, "w")
+    if K != Kw:
+        raise ValueError(f"gemm: K mismatch {K} vs {Kw}")
+    if out is None:
+        out = alloc(M, N) if alloc else torch.empty(M, N, dtype=torch.float32, device=a.device)
+    op, Mo, No, ldc = _rows(out, "out")
+    if Mo != M or No != N:
+        raise ValueError("gemm: out shape mismatch")
+    g = GemmArgs()
+    g.A, g.W, g.C = ap, wp, op
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldc = lda, ldw, ldc
+    if a2 is not None:
+        p2, M2, K2, ld2 = _rows(a2, "a2")
+        if M2 != M or K2 != K:
+            raise ValueError("gemm: a2 shape mismatch")
+        g.A2, g.lda2 = p2, ld2
+    if bias is not None:
+        _chk(bias, "bias")
+        g.bias = bias.data_ptr()
+    if res_mode != RES_NONE:
+        rp, Mr, Nr, ldr = _rows(res, "res")
+        if Mr != M or Nr != N:
+            raise ValueError("gemm: res shape mismatch")
+        g.res, g.ldres = rp, ldr
+    g.act, g.res_mode, g.batch = act, res_mode, 1
+    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+    return out
+
+
+def gemm_batched(a, w, out, bias=None, act=ACT_NONE):
+    """a [B,M,K], w [B,N,K], out [B,M,N] (all contiguous): B independent problems in one launch."""
+    for t, n in ((a, "a"), (w, "w"), (out, "out")):
+        _chk(t, n)
+        if not t.is_contiguous() or t.dim() != 3:
+            raise ValueError(f"gemm_batched: {n} must be contiguous 3-D")
+    B, M, K = a.shape
+    _, N, _ = w.shape
+    g = GemmArgs()
+    g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldc = K, K, N
+    g.batch = B
+    g.sA, g.sW, g.sC = M * K, N * K, M * N
+    if bias is not None:
+        g.bias, g.sBias = bias.data_ptr(), N
+    g.act = act
+    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32(batched)")
+    return out
+
+
+def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT_NONE, out=None, alloc=None):
+    """Channels-last convolution as implicit GEMM.  x [T*H*W, Cin]; w_packed [N, kh*kw*Cin] with
+    k = (ky*kw+kx)*Cin + c.  Returns [T*Ho*Wo, N]."""
+    _chk(x, "x")
+    _chk(w_packed, "w")
+    N = w_packed.shape[0]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    M = T * Ho * Wo
+    if out is None:
+        out = alloc(M, N) if alloc else torch.empty(M, N, dtype=torch.float32, device=x.device)
+    g = GemmArgs()
+    g.A, g.W, g.C = x.data_ptr(), w_packed.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, kh * kw * Cin
+    g.lda, g.ldw, g.ldc = Cin, kh * kw * Cin, N
+    if bias is not None:
+        g.bias = bias.data_ptr()
+    g.act, g.batch, g.conv = act, 1, 1
+    g.T, g.H, g.Wd, g.Cin, g.Ho, g.Wo = T, H, W, Cin, Ho, Wo
+    g.kh, g.kw, g.stride, g.pad = kh, kw, stride, pad
+    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32(conv)")
+    return out, Ho, Wo
+
+
+def layernorm(x, gamma, beta, eps=1e-5, r=None, out=None, alloc=None):
+    _chk(x, "x")
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    if out is None:
+        out = alloc(*x.shape) if alloc else torch.empty_like(x)
+    check(lib().tce_layernorm_f32(x.data_ptr(), r.data_ptr() if r is not None else None, gamma.data_ptr(),
+                                  beta.data_ptr(), out.data_ptr(), M, Cn, eps, _stream()), "tce_layernorm_f32")
+    return out
+
+
+def groupnorm_cl(x, gamma, beta, T, HW, Cn, G, eps=1e-5, relu=False, out=None, ws=None, alloc=None):
+    """x [T*HW, C] channels-last."""
+    _chk(x, "x")
+    nsplit = lib().tce_groupnorm_nsplit(HW)
+    if ws is None:
+        ws = alloc(T * G * nsplit * 3) if alloc else torch.empty(T * G * nsplit * 3, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = alloc(T * HW, Cn) if alloc else torch.empty(T * HW, Cn, dtype=torch.float32, device=x.device)
+    check(lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW,
+                                  Cn, G, eps, 1 if relu else 0, _stream()), "tce_groupnorm_f32")
+    return out
+
+
+def patch_embed(frames, w, b, gamma, beta, eps=1e-5, out=None, alloc=None):
+    _chk(frames, "frames")
+    T, c3, H, W = frames.shape
+    if c3 != 3 or not frames.is_contiguous():
+        raise ValueError("patch_embed: frames must be contiguous [T,3,H,W]")
+    Cn = w.shape[0]
+    Hp, Wp = (H + 3) // 4, (W + 3) // 4
+    if out is None:
+        out = alloc(T * Hp * Wp, Cn) if alloc else torch.empty(T * Hp * Wp, Cn, dtype=torch.float32, device=frames.device)
+    check(lib().tce_patch_embed_f32(frames.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    out.data_ptr(), T, H, W, Cn, eps, _stream()), "tce_patch_embed_f32")
+    return out, Hp, Wp
+
+
+def window_attn(qkv, qkv_bias, table, T, H, W, Cn, nH, shift, out=None, alloc=None):
+    _chk(qkv, "qkv")
+    if out is None:
+        out = alloc(T * H * W, Cn) if alloc else torch.empty(T * H * W, Cn, dtype=torch.float32, device=qkv.device)
+    check(lib().tce_window_attn_f32(qkv.data_ptr(), qkv_bias.data_ptr(), table.data_ptr(), out.data_ptr(), T, H, W, Cn,
+                                    nH, shift, _stream()), "tce_window_attn_f32")
+    return out
+
+
+def patch_merge_ln(x, gamma, beta, T, H, W, Cn, eps=1e-5, out=None, alloc=None):
+    _chk(x, "x")
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    if out is None:
+        out = alloc(T * H2 * W2, 4 * Cn) if alloc else torch.empty(T * H2 * W2, 4 * Cn, dtype=torch.float32, device=x.device)
+    check(lib().tce_patch_merge_ln_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), T, H, W, Cn, eps,
+                                       _stream()), "tce_patch_merge_ln_f32")
+    return out, H2, W2
+
+
+def mha_core(q, k, v, batch, nheads, Lq, Lk, ldq, ldk, ldv, sQ, sK, sV, out, ldo, sO, kmask=None, scale=None):
+    """Raw-strided attention core; q/k/v/out are tensors whose data_ptr() is the first element of
+    (batch 0, row 0, head 0).  Strides in floats."""
+    if scale is None:
+        scale = 32 ** -0.5
+    check(lib().tce_mha_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, nheads, Lq, Lk, ldq, ldk,
+                            ldv, ldo, sQ, sK, sV, sO, kmask.data_ptr() if kmask is not None else None, scale,
+                            _stream()), "tce_mha_f32")
+    return out
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Drop-in for MultiScaleDeformableAttention_update.ms_deform_attn_forward (ms_deform_attn_func.py:26-27)."""
+    for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+        _chk(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} tensor has to be contiguous")
+    if not (spatial_shapes.is_cuda and level_start_index.is_cuda and spatial_shapes.dtype == torch.int64):
+        raise RuntimeError("spatial_shapes / level_start_index must be CUDA int64 tensors")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    out = torch.empty(N, Lq, M * D, dtype=torch.float32, device=value.device)
+    check(lib().tce_ms_deform_attn_forward_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                               sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), N, S,
+                                               M, D, Lq, L, P, _stream()), "tce_ms_deform_attn_forward_f32")
+    return out
+
+
+def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_frame, out=None, alloc=None):
+    _chk(value, "value")
+    if out is None:
+        out = alloc(N * Lq, M * 32) if alloc else torch.empty(N * Lq, M * 32, dtype=torch.float32, device=value.device)
+    arr = (C.c_int32 * (2 * L))(*[int(v) for hw in shapes_hw for v in hw])
+    check(lib().tce_msda_fused_f32(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), arr, N, S, M, Lq,
+                                   L, P, ref_dim, 1 if ref_per_frame else 0, _stream()), "tce_msda_fused_f32")
+    return out
+
+
+def pos_sine2d(T, h, w, F, device, add=None, out=None, alloc=None):
+    if out is None:
+        out = alloc(T * h * w, 2 * F) if alloc else torch.empty(T * h * w, 2 * F, dtype=torch.float32, device=device)
+    check(lib().tce_pos_sine2d_f32(out.data_ptr(), add.data_ptr() if add is not None else None, T, h, w, F, _stream()),
+          "tce_pos_sine2d_f32")
+    return out
+
+
+def resize_nearest(x, T, h, w, ho, wo, Cn, add=None, out=None, alloc=None):
+    _chk(x, "x")
+    if out is None:
+        out = alloc(T * ho * wo, Cn) if alloc else torch.empty(T * ho * wo, Cn, dtype=torch.float32, device=x.device)
+    check(lib().tce_resize_nearest_f32(x.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), T, h,
+                                       w, ho, wo, Cn, _stream()), "tce_resize_nearest_f32")
+    return out
+
+
+def resize_bilinear(x, T, h, w, ho, wo, Cn, add=None, out=None, alloc=None):
+    _chk(x, "x")
+    if out is None:
+        out = alloc(T * ho * wo, Cn) if alloc else torch.empty(T * ho * wo, Cn, dtype=torch.float32, device=x.device)
+    check(lib().tce_resize_bilinear_f32(x.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), T, h,
+                                        w, ho, wo, Cn, _stream()), "tce_resize_bilinear_f32")
+    return out
+
+
+def add(a, b, out=None, alloc=None):
+    """out = a + b with b broadcast over leading dims (b.numel() divides a.numel())."""
+    _chk(a, "a")
+    if out is None:
+        out = alloc(*a.shape) if alloc else torch.empty_like(a)
+    check(lib().tce_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), _stream()), "tce_add_f32")
+    return out
+
+
+def sigmoid(x, out=None, alloc=None):
+    if out is None:
+        out = alloc(*x.shape) if alloc else torch.empty_like(x)
+    check(lib().tce_sigmoid_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tce_sigmoid_f32")
+    return out
+
+
+def box_refine(tmp, ref, out=None, alloc=None):
+    n = tmp.numel() // 4
+    ref_dim = ref.shape[-1]
+    if out is None:
+        out = alloc(*tmp.shape) if alloc else torch.empty_like(tmp)
+    check(lib().tce_box_refine_f32(tmp.data_ptr(), ref.data_ptr(), out.data_ptr(), n, ref_dim, _stream()),
+          "tce_box_refine_f32")
+    return out
+
+
+def mask_pack(params, nl, T, Q, Cm, w0f, tail):
+    check(lib().tce_mask_pack_f32(params.data_ptr(), w0f.data_ptr(), tail.data_ptr(), nl, T, Q, Cm, _stream()),
+          "tce_mask_pack_f32")
+
+
+def mask_tail(G, tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px=4):
+    check(lib().tce_mask_tail_f32(G.data_ptr(), tail.data_ptr(), refs.data_ptr(), ref_ld, masks.data_ptr(), nl, T, Q, h,
+                                  w, float(img_h), float(img_w), stride_px, _stream()), "tce_mask_tail_f32")
+    return masks
