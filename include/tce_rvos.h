@@ -76,6 +76,13 @@ int tce_patch_embed_f32(const float* frames, const float* w, const float* b, con
 int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out, int32_t T,
                         int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shift, tceStream stream);
 
+/* Video-Swin 3-D (shifted-)window attention core over tokens [T, H, W] (nominal window (8,7,7), shrunk to the
+ * grid where it is smaller; temporal/spatial shift (4,3,3) when `shifted` and the dim spans > 1 window; padded
+ * tokens carry qkv = bias).  Same operands as tce_window_attn_f32; bias_table is [(2*8-1)*13*13, nH].
+ * Reference: video_swin_transformer.py:71-84,138-169,215-249,316-329. */
+int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out, int32_t T,
+                          int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shifted, tceStream stream);
+
 /* Swin PatchMerging front half: gather 2x2 neighbours in the order (0,0),(1,0),(0,1),(1,1) with odd-size zero
  * padding, LayerNorm(4C).  x [T,H,W,C] -> out [T*ceil(H/2)*ceil(W/2), 4C].  Reference: swin_transformer.py:273-297. */
 int tce_patch_merge_ln_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t T, int32_t H,
@@ -126,6 +133,8 @@ int tce_resize_bilinear_f32(const float* in, const float* add, float* out, int32
  *   tce_box_refine_f32 out[n,4] = sigmoid(tmp[n,4] + inverse_sigmoid(ref[n,ref_dim]) on the first ref_dim coords)
  *                      (tce_deformable_transformer.py:761-771, util/misc.py:555-559) */
 int tce_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t nb, tceStream stream);
+/*   tce_tile_f32       out[i] = src[i % n_src] for i < n_src*reps (row broadcast: memory_bus / sentence feature) */
+int tce_tile_f32(const float* src, float* out, int64_t n_src, int64_t reps, tceStream stream);
 int tce_sigmoid_f32(const float* x, float* out, int64_t n, tceStream stream);
 int tce_box_refine_f32(const float* tmp, const float* ref, float* out, int32_t n, int32_t ref_dim, tceStream stream);
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),
     "tce_patch_embed_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
     "tce_window_attn_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_window_attn3d_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_patch_merge_ln_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
     "tce_mha_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, c_f, f32, c_f]),
     "tce_ms_deform_attn_forward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
@@ -41,6 +42,7 @@ SIGNATURES = {
     "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_bilinear_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_add_f32": (i32, [c_f, c_f, c_f, i64, i64, c_f]),
+    "tce_tile_f32": (i32, [c_f, c_f, i64, i64, c_f]),
     "tce_sigmoid_f32": (i32, [c_f, c_f, i64, c_f]),
     "tce_box_refine_f32": (i32, [c_f, c_f, c_f, i32, i32, c_f]),
     "tce_mask_pack_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, c_f]),

@@ -247,6 +247,158 @@ __global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ Q, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Video-Swin 3-D window attention (video_swin_transformer.py:71-84,138-169,215-249,316-329).
+// One workgroup per (window, head); the window's K/V (<= 8*7*7 = 392 tokens x 32) and this head's column of
+// the relative-position table live in LDS for the whole workgroup.  Reference quirks reproduced:
+//   * windows SHRINK to the feature size when it is <= the nominal window (no padding in that dim, no shift);
+//   * the bias index is relative_position_index[:N,:N] of the FULL (8,7,7) window, i.e. token n of a shrunken
+//     window is re-read in full-window coordinates (n/49, (n%49)/7, n%7);
+//   * padded tokens (temporal padding when T is not a multiple of the depth) carry qkv = bias and are not masked;
+//   * the -100 shift mask uses region ids on the padded, shifted grid; a dim with shift 0 has one region.
+// ---------------------------------------------------------------------------------------------------
+struct Win3D {
+  int D, H, W;        // token grid (frames, rows, cols)
+  int wd, wh, ww;     // effective window
+  int sd, sh, sw;     // effective shift (0 if the block is not shifted)
+  int Dp, Hp, Wp;     // padded grid
+  int fd, fh, fw;     // nominal (full) window: 8,7,7
+};
+
+__global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ qkv_bias,
+                                                            const float* __restrict__ table, float* __restrict__ out,
+                                                            Win3D g, int C, int nH, int table_rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  const int N = g.wd * g.wh * g.ww;
+  float* sK = smem3;                 // [N][32]
+  float* sV = sK + N * HD;           // [N][32]
+  float* sB = sV + N * HD;           // [table_rows]
+  int* sSrc = reinterpret_cast<int*>(sB + table_rows);  // [N] source token row or -1 (padded)
+  int* sRid = sSrc + N;              // [N] mask region id
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x % nH;
+  int widx = blockIdx.x / nH;
+  const int nwx = g.Wp / g.ww, nwy = g.Hp / g.wh;
+  const int bx = widx % nwx; widx /= nwx;
+  const int by = widx % nwy;
+  const int bd = widx / nwy;
+  const int C3 = 3 * C;
+  for (int n = tid; n < N; n += 256) {
+    const int x = n % g.ww, y = (n / g.ww) % g.wh, d = n / (g.ww * g.wh);
+    const int dd = bd * g.wd + d, yy = by * g.wh + y, xx = bx * g.ww + x;  // shifted-grid coordinates
+    int ds = dd + g.sd, ys = yy + g.sh, xs = xx + g.sw;
+    if (ds >= g.Dp) ds -= g.Dp;
+    if (ys >= g.Hp) ys -= g.Hp;
+    if (xs >= g.Wp) xs -= g.Wp;
+    sSrc[n] = (ds < g.D && ys < g.H && xs < g.W) ? (ds * g.H + ys) * g.W + xs : -1;
+    const int rd = g.sd > 0 ? (dd < g.Dp - g.wd ? 0 : (dd < g.Dp - g.sd ? 1 : 2)) : 0;
+    const int ry = g.sh > 0 ? (yy < g.Hp - g.wh ? 0 : (yy < g.Hp - g.sh ? 1 : 2)) : 0;
+    const int rx = g.sw > 0 ? (xx < g.Wp - g.ww ? 0 : (xx < g.Wp - g.sw ? 1 : 2)) : 0;
+    sRid[n] = (rd * 3 + ry) * 3 + rx;
+  }
+  for (int i = tid; i < table_rows; i += 256) sB[i] = table[(long long)i * nH + h];
+  __syncthreads();
+  for (int i = tid; i < N * 8; i += 256) {
+    const int n = i >> 3, d4 = i & 7;
+    const int srow = sSrc[n];
+    f32x4 kv, vv;
+    if (srow >= 0) {
+      const float* p = qkv + (long long)srow * C3 + h * HD + d4 * 4;
+      kv = *reinterpret_cast<const f32x4*>(p + C);
+      vv = *reinterpret_cast<const f32x4*>(p + 2 * C);
+    } else {
+      kv = *reinterpret_cast<const f32x4*>(qkv_bias + C + h * HD + d4 * 4);
+      vv = *reinterpret_cast<const f32x4*>(qkv_bias + 2 * C + h * HD + d4 * 4);
+    }
+    *reinterpret_cast<f32x4*>(&sK[n * HD + d4 * 4]) = kv;
+    *reinterpret_cast<f32x4*>(&sV[n * HD + d4 * 4]) = vv;
+  }
+  __syncthreads();
+  const bool masked = (g.sd | g.sh | g.sw) != 0;
+  const float scale = 0.17677669529663687f;
+  const int fhw = g.fh * g.fw;
+  for (int q0 = 0; q0 < N; q0 += 256) {
+    const int i = q0 + tid;
+    if (i >= N) break;
+    const int srow = sSrc[i];
+    const float* qp = srow >= 0 ? qkv + (long long)srow * C3 + h * HD : qkv_bias + h * HD;
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[d4 * 4 + j] = v[j] * scale;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    // full-window coordinates of flat index i (the [:N,:N] slicing quirk)
+    const int id_ = i / fhw, iy_ = (i % fhw) / g.fw, ix_ = i % g.fw;
+    const int rid = sRid[i];
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 32) {
+      float s[32];
+      float tmax = -3.0e38f;
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        const int j = k0 + jj;
+        float a = -3.0e38f;
+        if (j < N) {
+          const f32x4* kp = reinterpret_cast<const f32x4*>(&sK[j * HD]);
+          a = 0.f;
+#pragma unroll
+          for (int d4 = 0; d4 < 8; ++d4) {
+            const f32x4 kv = kp[d4];
+            a = fmaf(q[d4 * 4 + 0], kv[0], a);
+            a = fmaf(q[d4 * 4 + 1], kv[1], a);
+            a = fmaf(q[d4 * 4 + 2], kv[2], a);
+            a = fmaf(q[d4 * 4 + 3], kv[3], a);
+          }
+          const int jd = j / fhw, jy = (j % fhw) / g.fw, jx = j % g.fw;
+          const int ridx = ((id_ - jd + g.fd - 1) * (2 * g.fh - 1) + (iy_ - jy + g.fh - 1)) * (2 * g.fw - 1) +
+                           (ix_ - jx + g.fw - 1);
+          a += sB[ridx];
+          if (masked && sRid[j] != rid) a += -100.0f;
+        }
+        s[jj] = a;
+        tmax = fmaxf(tmax, a);
+      }
+      const float mnew = fmaxf(m, tmax);
+      const float corr = __expf(m - mnew);
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= corr;
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        const int j = k0 + jj;
+        if (j < N) {
+          const float pj = __expf(s[jj] - mnew);
+          l += pj;
+          const f32x4* vp = reinterpret_cast<const f32x4*>(&sV[j * HD]);
+#pragma unroll
+          for (int d4 = 0; d4 < 8; ++d4) {
+            const f32x4 vv = vp[d4];
+            o[d4 * 4 + 0] = fmaf(pj, vv[0], o[d4 * 4 + 0]);
+            o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
+            o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]);
+            o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
+          }
+        }
+      }
+      m = mnew;
+    }
+    if (srow >= 0) {
+      const float inv = 1.0f / l;
+      float* po = out + (long long)srow * C + h * HD;
+#pragma unroll
+      for (int d4 = 0; d4 < 8; ++d4) {
+        f32x4 v = {o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv};
+        *reinterpret_cast<f32x4*>(po + d4 * 4) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
@@ -283,5 +435,42 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
   hipLaunchKernelGGL((mha_kernel<32>), grid, dim3(nthr), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
                      ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
   TCE_CHECK_LAUNCH("tce_mha_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
+                                     int32_t T, int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shifted,
+                                     tceStream stream) {
+  TCE_CHECK_ARG(qkv && qkv_bias && bias_table && out, "tce_window_attn3d_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && nH > 0 && C == nH * 32, "tce_window_attn3d_f32: need C == nH*32");
+  TCE_CHECK_ARG(tce_aligned16(qkv) && tce_aligned16(qkv_bias) && tce_aligned16(out),
+                "tce_window_attn3d_f32: pointers must be 16-byte aligned");
+  Win3D g;
+  g.D = T; g.H = H; g.W = W;
+  g.fd = 8; g.fh = 7; g.fw = 7;
+  const int size[3] = {T, H, W}, full[3] = {8, 7, 7};
+  int win[3], sh[3], pad[3];
+  for (int i = 0; i < 3; ++i) {  // get_window_size: shrink (and never shift) a dim that fits in one window
+    const bool fits = size[i] <= full[i];
+    win[i] = fits ? size[i] : full[i];
+    sh[i] = (fits || !shifted) ? 0 : full[i] / 2;
+    pad[i] = (size[i] + win[i] - 1) / win[i] * win[i];
+  }
+  g.wd = win[0]; g.wh = win[1]; g.ww = win[2];
+  g.sd = sh[0]; g.sh = sh[1]; g.sw = sh[2];
+  g.Dp = pad[0]; g.Hp = pad[1]; g.Wp = pad[2];
+  const int N = g.wd * g.wh * g.ww;
+  const int table_rows = (2 * 8 - 1) * 13 * 13;
+  const int nwin = (g.Dp / g.wd) * (g.Hp / g.wh) * (g.Wp / g.ww);
+  const size_t smem = (size_t)(2 * N * 32 + table_rows) * sizeof(float) + (size_t)2 * N * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn3d_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(window_attn3d_kernel, dim3(nwin * nH), dim3(256), smem, (hipStream_t)stream, qkv, qkv_bias,
+                     bias_table, out, g, C, nH, table_rows);
+  TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
   return TCE_OK;
 }

@@ -80,6 +80,12 @@ __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, c
   if (i < n) out[i] = a[i] + b[i % nb];
 }
 
+__global__ void __launch_bounds__(256) tile_kernel(const float* __restrict__ src, float* __restrict__ out, long long n,
+                                                   long long n_src) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = src[i % n_src];
+}
+
 __global__ void __launch_bounds__(256) sigmoid_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                       long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -214,6 +220,15 @@ extern "C" int tce_add_f32(const float* a, const float* b, float* out, int64_t n
   hipLaunchKernelGGL(add_kernel, dim3(tce_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n,
                      (long long)nb);
   TCE_CHECK_LAUNCH("tce_add_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_tile_f32(const float* src, float* out, int64_t n_src, int64_t reps, tceStream stream) {
+  TCE_CHECK_ARG(src && out && n_src > 0 && reps > 0, "tce_tile_f32: bad arguments");
+  const long long n = (long long)n_src * reps;
+  hipLaunchKernelGGL(tile_kernel, dim3(tce_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, out, n,
+                     (long long)n_src);
+  TCE_CHECK_LAUNCH("tce_tile_f32");
   return TCE_OK;
 }
 

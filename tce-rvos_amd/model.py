@@ -1,0 +1,355 @@
+"""ReferFormer drop-in: the reference's `build_model(args)` / `model(samples, captions, targets)` boundary
+(models/__init__.py:4-5, models/tce_rvos.py:194-393, 638-719) over a flat MI355X pipeline.
+
+The module tree exists only to own parameters under the reference's state-dict names (so reference
+checkpoints load with `load_state_dict`); `forward` is NOT a module graph: it is one straight-line program
+that launches hand-written HIP kernels (libtce_rvos.so) on token-major / channels-last activations living in
+a bump arena.  PyTorch supplies device memory, the stream and the (third-party) RoBERTa text encoder.
+"""
+import math
+from collections import OrderedDict
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import ModelConfig, config_from_args, index_buffers, param_shapes
+from .weights import synth_tensor
+
+ACT_RELU, ACT_GELU = ops.ACT_RELU, ops.ACT_GELU
+RES_ADD, RES_MUL = ops.RES_ADD, ops.RES_MUL
+
+
+class NestedTensor(object):
+    """util/misc.py:380-400"""
+
+    def __init__(self, tensors, mask: Optional[torch.Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), self.mask.to(device) if self.mask is not None else None)
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def __repr__(self):
+        return str(self.tensors)
+
+
+def nested_tensor_from_videos_list(videos_list: List[torch.Tensor], size_divisibility=1):
+    """util/misc.py:354-377"""
+    max_size = [max(s) for s in zip(*[list(v.shape) for v in videos_list])]
+    if size_divisibility > 1:
+        st = size_divisibility
+        max_size[-2] = (max_size[-2] + st - 1) // st * st
+        max_size[-1] = (max_size[-1] + st - 1) // st * st
+    b = len(videos_list)
+    t, c, h, w = max_size
+    vids = torch.zeros([b, t, c, h, w], dtype=videos_list[0].dtype, device=videos_list[0].device)
+    masks = torch.ones((b, t, h, w), dtype=torch.bool, device=videos_list[0].device)
+    for v, pv, m in zip(videos_list, vids, masks):
+        pv[:v.shape[0], :, :v.shape[2], :v.shape[3]].copy_(v)
+        m[:v.shape[0], :v.shape[2], :v.shape[3]] = False
+    return NestedTensor(vids, masks)
+
+
+class _Node(nn.Module):
+    """Parameter container; carries no computation."""
+
+
+class SyntheticTokenizer:
+    """Offline stand-in for RobertaTokenizerFast (its vocabulary is a network download): whitespace words
+    hashed into the RoBERTa id range, <s>=0 ... </s>=2.  Deterministic; NOT the real BPE."""
+
+    def __call__(self, captions, max_len=None):
+        import zlib
+        rows = []
+        for c in captions:
+            ids = [0] + [3 + zlib.crc32(wd.encode()) % 50262 for wd in c.lower().split()] + [2]
+            rows.append(ids)
+        L = max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), 1, dtype=torch.long)
+        att = torch.zeros((len(rows), L), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r)
+            att[i, :len(r)] = 1
+        return ids, att
+
+
+class ReferFormer(nn.Module):
+    def __init__(self, cfg: ModelConfig, args=None, text_encoder=None, tokenizer=None, init_salt=0):
+        super().__init__()
+        self.cfg = cfg
+        self.args = args
+        self.num_queries = cfg.num_queries
+        self.hidden_dim = cfg.hidden_dim
+        self.num_feature_levels = cfg.num_feature_levels
+        self.num_frames = cfg.num_frames
+        self.mask_dim = cfg.mask_dim
+        self.aux_loss = cfg.aux_loss
+        self.with_box_refine = cfg.with_box_refine
+        self.mask_out_stride = 4
+        self.mask_feat_stride = 4
+        if cfg.hidden_dim != 256 or cfg.nheads != 8:
+            raise NotImplementedError("kernels are built for hidden_dim=256, nheads=8 (head_dim 32)")
+        if cfg.num_feature_levels != 4:
+            raise NotImplementedError("num_feature_levels must be 4")
+        shapes = param_shapes(cfg)
+        for key, shape in shapes.items():
+            node, leaf = self._node_for(key)
+            node.register_parameter(leaf, nn.Parameter(synth_tensor(key, shape, init_salt), requires_grad=True))
+        for key, shape in index_buffers(cfg).items():
+            node, leaf = self._node_for(key)
+            node.register_buffer(leaf, self._rel_index(cfg))
+        if cfg.with_box_refine:  # one tensor, two names (tce_rvos.py:124)
+            self.transformer.decoder.add_module("bbox_embed", self.bbox_embed)
+        if text_encoder is None:
+            text_encoder = build_text_encoder(args)
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer if tokenizer is not None else SyntheticTokenizer()
+        if args is not None and getattr(args, "freeze_text_encoder", False):
+            for p in self.text_encoder.parameters():
+                p.requires_grad_(False)
+        self._packed = None
+        self._arena = None
+        self._shape_cache = {}
+        self.arena_bytes = None  # override to force an arena size
+
+    # ---------------------------------------------------------------- parameter tree
+    def _node_for(self, key):
+        parts = key.split(".")
+        node = self
+        for p in parts[:-1]:
+            nxt = node._modules.get(p)
+            if nxt is None:
+                nxt = _Node()
+                node.add_module(p, nxt)
+            node = nxt
+        return node, parts[-1]
+
+    @staticmethod
+    def _rel_index(cfg):
+        if cfg.video:
+            wd, wh, ww = cfg.video_window
+            co = torch.stack(torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing="ij")).flatten(1)
+            rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0).contiguous()
+            rel[:, :, 0] += wd - 1
+            rel[:, :, 1] += wh - 1
+            rel[:, :, 2] += ww - 1
+            rel[:, :, 0] *= (2 * wh - 1) * (2 * ww - 1)
+            rel[:, :, 1] *= 2 * ww - 1
+            return rel.sum(-1)
+        ws = cfg.window_size
+        co = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+        rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += ws - 1
+        rel[:, :, 1] += ws - 1
+        rel[:, :, 0] *= 2 * ws - 1
+        return rel.sum(-1)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._shape_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self._packed = None
+        self._shape_cache = {}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def repack(self):
+        """Call after mutating parameters in place (the packed kernel operands are derived copies)."""
+        self._packed = None
+        self._shape_cache = {}
+
+    # ---------------------------------------------------------------- weight packing
+    def _pack(self):
+        cfg = self.cfg
+        d = cfg.hidden_dim
+        w = {}
+        # state_dict() lists aliased tensors under every name (named_parameters() de-duplicates them)
+        sd = {k: v for k, v in self.state_dict(keep_vars=True).items()
+              if not k.startswith("text_encoder.") and v.is_floating_point()}
+        for k, v in sd.items():
+            if not v.is_cuda or v.dtype != torch.float32:
+                raise RuntimeError(f"parameter {k} must be a CUDA float32 tensor (model.to('cuda') first); "
+                                   f"there is no CPU path")
+            w[k] = v.detach()
+        with torch.no_grad():
+            # MSDA: one projection for (sampling offsets | attention logits)
+            for k in list(sd):
+                if k.endswith("sampling_offsets.weight"):
+                    pre = k[:-len("sampling_offsets.weight")]
+                    w[pre + "offaw.weight"] = torch.cat([sd[k], sd[pre + "attention_weights.weight"]], 0).contiguous()
+                    w[pre + "offaw.bias"] = torch.cat([sd[pre + "sampling_offsets.bias"],
+                                                       sd[pre + "attention_weights.bias"]], 0).contiguous()
+                if k.endswith("in_proj_weight"):
+                    pre = k[:-len("in_proj_weight")]
+                    W, B = sd[k].detach(), sd[pre + "in_proj_bias"].detach()
+                    w[pre + "q.w"], w[pre + "k.w"], w[pre + "v.w"] = W[:d], W[d:2 * d], W[2 * d:]
+                    w[pre + "q.b"], w[pre + "k.b"], w[pre + "v.b"] = B[:d], B[d:2 * d], B[2 * d:]
+                    w[pre + "qk.w"], w[pre + "qk.b"] = W[:2 * d], B[:2 * d]
+                if v_is_conv(sd[k]) and sd[k].shape[-1] == 3:
+                    w[k + ":cl"] = sd[k].detach().permute(0, 2, 3, 1).reshape(sd[k].shape[0], -1).contiguous()
+            if cfg.video:
+                w["backbone.0.body.patch_embed.proj.weight:2d"] = \
+                    sd["backbone.0.body.patch_embed.proj.weight"].detach().squeeze(2).contiguous()
+        self._packed = w
+        return w
+
+    # ---------------------------------------------------------------- per-shape constants
+    def _shape_consts(self, T, H0, W0, device):
+        key = (T, H0, W0)
+        c = self._shape_cache.get(key)
+        if c is not None:
+            return c
+        cfg, w = self.cfg, self._packed
+        Hp, Wp = (H0 + 3) // 4, (W0 + 3) // 4
+        sizes = [(Hp, Wp)]
+        for _ in range(3):
+            h, ww = sizes[-1]
+            sizes.append(((h + 1) // 2, (ww + 1) // 2))
+        h5, w5 = sizes[3]
+        lvl_sizes = [sizes[1], sizes[2], sizes[3], ((h5 + 2 - 3) // 2 + 1, (w5 + 2 - 3) // 2 + 1)]
+        S = sum(h * ww for h, ww in lvl_sizes)
+        starts = [0]
+        for h, ww in lvl_sizes[:-1]:
+            starts.append(starts[-1] + h * ww)
+        F = cfg.hidden_dim // 2
+        c = dict(sizes=sizes, lvl_sizes=lvl_sizes, S=S, starts=starts)
+        # backbone-level position maps (frame independent for un-padded clips): [h*w, 256]
+        c["pos"] = [ops.pos_sine2d(1, h, ww, F, device) for (h, ww) in sizes]
+        # encoder position = sine + level embedding, concatenated over levels: [S, 256]
+        lp = torch.empty(S, cfg.hidden_dim, dtype=torch.float32, device=device)
+        for l, (h, ww) in enumerate(lvl_sizes):
+            ops.pos_sine2d(1, h, ww, F, device, add=w["transformer.level_embed"][l], out=lp[starts[l]:starts[l] + h * ww])
+        c["lvl_pos"] = lp
+        # encoder reference points (pixel centres), get_reference_points :572-589 with valid_ratios == 1
+        refs = []
+        for (h, ww) in lvl_sizes:
+            ry, rx = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=torch.float32),
+                                    torch.linspace(0.5, ww - 0.5, ww, dtype=torch.float32), indexing="ij")
+            refs.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / h), -1))
+        c["enc_ref"] = torch.cat(refs, 0).to(device).contiguous()
+        # VLBlock reduced grids (segmentation.py:339-344): stage k=1..4 <-> sizes[k-1], sr = 8,4,2,1
+        red = {}
+        for stage, sr in ((1, 8), (2, 4), (3, 2), (4, 1)):
+            h, ww = sizes[stage - 1]
+            if sr > 1:
+                nh_, nw_ = int(h * 1.0 / sr), int(ww * 1.0 / sr)
+                red[stage] = (nh_, nw_, ops.resize_nearest(c["pos"][stage - 1], 1, h, ww, nh_, nw_, cfg.hidden_dim))
+        c["red"] = red
+        self._shape_cache[key] = c
+        return c
+
+    def _text_pos(self, L, device):
+        key = ("text_pos", L)
+        tp = self._shape_cache.get(key)
+        if tp is None:
+            x = torch.arange(1, L + 1, dtype=torch.float32)
+            x = x / (x[-1:] + 1e-6) * (2 * math.pi)
+            dim_t = torch.arange(self.cfg.hidden_dim, dtype=torch.float32)
+            dim_t = 10000.0 ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / self.cfg.hidden_dim)
+            px = x[:, None] / dim_t
+            tp = torch.stack((px[:, 0::2].sin(), px[:, 1::2].cos()), dim=2).flatten(1).to(device).contiguous()
+            self._shape_cache[key] = tp
+        return tp
+
+    def _get_arena(self, T, H0, W0, device):
+        tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
+        need = self.arena_bytes or int(tok0 * 4 * (2048 * 2.2 + 256 * 24) + (256 << 20))
+        if self._arena is None or self._arena.buf.numel() < need or self._arena.device != torch.device(device):
+            self._arena = ops.Arena(device, need)
+        return self._arena
+
+    # ---------------------------------------------------------------- the boundary
+    def forward(self, samples, captions, targets):
+        """models/tce_rvos.py:194.  samples: NestedTensor([B,T,3,H,W],[B,T,H,W]) or list of [T,3,H,W];
+        captions: list[str] (or a LongTensor [B,L] of token ids); targets: list[dict] with 'size'."""
+        if not isinstance(samples, NestedTensor) and not (hasattr(samples, "tensors") and hasattr(samples, "mask")):
+            samples = nested_tensor_from_videos_list(samples)
+        vids, mask = samples.tensors, samples.mask
+        if isinstance(captions, (list, tuple)):
+            if not isinstance(captions[0], str):
+                raise ValueError("Please mask sure the caption is a list of string")
+            b = len(captions)
+        else:
+            b = captions.shape[0]
+        if vids.dim() == 4:
+            vids = vids[None]
+        if b != 1 or vids.shape[0] != 1:
+            raise NotImplementedError("one clip per forward (B = 1): the reference mixes clips inside a batch "
+                                      "(FTF token attention, IQT) so batching changes results; shard clips instead")
+        if "valid_indices" in targets[0]:
+            raise NotImplementedError("valid_indices (A2D/JHMDB single-frame path) is outside the hot path")
+        if not vids.is_cuda:
+            raise RuntimeError("inputs must be on the GPU: this path has no CPU implementation")
+        if mask is not None and bool(mask.any()):
+            raise NotImplementedError("padded clips are not supported (a single clip is never padded)")
+        frames = vids[0].to(torch.float32).contiguous()
+        hid, pooled = self.forward_text_encoder(captions, frames.device)
+        size = targets[0]["size"]
+        img_h, img_w = float(size[0]), float(size[1])
+        return self.forward_features(frames, hid[0], pooled[0], img_h, img_w)
+
+    @torch.no_grad()
+    def forward_text_encoder(self, captions, device):
+        """tce_rvos.py:406-424 up to the RoBERTa outputs (third-party arithmetic, runs on PyTorch-ROCm)."""
+        if isinstance(captions, (list, tuple)):
+            ids, att = self.tokenizer(list(captions))
+        else:
+            ids, att = captions, torch.ones_like(captions)
+        if bool((att != 1).any()):
+            raise NotImplementedError("padded captions (B > 1) are not supported")
+        enc = self.text_encoder(input_ids=ids.to(device), attention_mask=att.to(device))
+        return enc.last_hidden_state.float(), enc.pooler_output.float()
+
+    @torch.no_grad()
+    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w):
+        """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768]."""
+        from .pipeline import run_clip
+        if self._packed is None:
+            self._pack()
+        return run_clip(self, frames, text_hidden.contiguous(), text_pooled.contiguous(), img_h, img_w)
+
+
+def v_is_conv(t):
+    return t.dim() == 4
+
+
+def build_text_encoder(args=None):
+    """RoBERTa-base architecture from the installed `transformers` package.  The reference fetches
+    'roberta-base' by name (tce_rvos.py:136-137): no network here, so weights come from a local directory when
+    `args.text_encoder_path` is given, else random initialisation under a fixed seed."""
+    import transformers
+    path = getattr(args, "text_encoder_path", None) if args is not None else None
+    if path:
+        return transformers.RobertaModel.from_pretrained(path)
+    layers = getattr(args, "text_encoder_layers", 12) if args is not None else 12
+    cfg = transformers.RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                                     num_hidden_layers=layers)
+    st = torch.random.get_rng_state()
+    torch.manual_seed(0)
+    m = transformers.RobertaModel(cfg)
+    torch.random.set_rng_state(st)
+    return m.eval()
+
+
+class _Stub(nn.Module):
+    """Stands where the reference returns its training criterion / COCO post-processors (out of scope)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(f"{self.what} is training / dataset glue outside the MI355X hot path")
+
+
+def build_model(args):
+    """models/__init__.py:4-5 -> tce_rvos.build :638-719.  Returns (model, criterion, postprocessors)."""
+    cfg = config_from_args(args)
+    model = ReferFormer(cfg, args=args)
+    return model, _Stub("SetCriterion"), {"segm": _Stub("PostProcessSegm")}

@@ -190,6 +190,15 @@ def window_attn(qkv, qkv_bias, table, T, H, W, Cn, nH, shift, out=None, alloc=No
     return out
 
 
+def window_attn3d(qkv, qkv_bias, table, T, H, W, Cn, nH, shifted, out=None, alloc=None):
+    _chk(qkv, "qkv")
+    if out is None:
+        out = alloc(T * H * W, Cn) if alloc else torch.empty(T * H * W, Cn, dtype=torch.float32, device=qkv.device)
+    check(lib().tce_window_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), table.data_ptr(), out.data_ptr(), T, H, W,
+                                      Cn, nH, 1 if shifted else 0, _stream()), "tce_window_attn3d_f32")
+    return out
+
+
 def patch_merge_ln(x, gamma, beta, T, H, W, Cn, eps=1e-5, out=None, alloc=None):
     _chk(x, "x")
     H2, W2 = (H + 1) // 2, (W + 1) // 2
@@ -273,6 +282,15 @@ def add(a, b, out=None, alloc=None):
     return out
 
 
+def tile(src, reps, out=None, alloc=None):
+    """out = src repeated `reps` times along a new leading axis (flattened)."""
+    _chk(src, "src")
+    if out is None:
+        out = alloc(reps * src.numel()) if alloc else torch.empty(reps * src.numel(), dtype=torch.float32, device=src.device)
+    check(lib().tce_tile_f32(src.data_ptr(), out.data_ptr(), src.numel(), reps, _stream()), "tce_tile_f32")
+    return out
+
+
 def sigmoid(x, out=None, alloc=None):
     if out is None:
         out = alloc(*x.shape) if alloc else torch.empty_like(x)
@@ -299,3 +317,24 @@ def mask_tail(G, tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride
     check(lib().tce_mask_tail_f32(G.data_ptr(), tail.data_ptr(), refs.data_ptr(), ref_ld, masks.data_ptr(), nl, T, Q, h,
                                   w, float(img_h), float(img_w), stride_px, _stream()), "tce_mask_tail_f32")
     return masks
+
+
+def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=ACT_NONE, res=None, ldres=0,
+            res_mode=RES_NONE, batch=1, sA=0, sA2=0, sW=0, sBias=0, sC=0, sRes=0):
+    """Fully explicit form: tensors only provide base pointers (slices / views welcome); all sizes and
+    strides (in floats) are given by the caller.  Used by the model for frame-batched launches where the
+    addend (a positional map) is shared by all frames (sA2 = 0) or the output is a level slice of [T,S,C]."""
+    g = GemmArgs()
+    g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldc = lda, ldw, ldc
+    if a2 is not None:
+        g.A2, g.lda2 = a2.data_ptr(), lda2
+    if bias is not None:
+        g.bias = bias.data_ptr()
+    if res_mode != RES_NONE:
+        g.res, g.ldres = res.data_ptr(), ldres
+    g.act, g.res_mode, g.batch = act, res_mode, batch
+    g.sA, g.sA2, g.sW, g.sBias, g.sC, g.sRes = sA, sA2, sW, sBias, sC, sRes
+    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+    return out

@@ -1,0 +1,393 @@
+"""The per-clip forward as one straight-line launch program (reference: models/tce_rvos.py:194-393).
+
+Data layout: every activation is token-major fp32 [tokens, C] with tokens = (frame, y, x) -- the layout both
+the Swin blocks ([B, H*W, C]) and the deformable transformer ([N, S, C]) already want, and the channels-last
+form the implicit-GEMM convolutions read.  The encoder sequence of a frame is the concatenation of its four
+levels (S rows), so `memory` is [T, S, 256] exactly as the reference returns it.  Position maps are frame
+independent for un-padded clips and are shared by all frames through frame-batched launches (stride 0).
+"""
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_RELU, RES_ADD, RES_MUL, gemm_ex
+
+D = 256
+NH = 8
+
+
+def _lin(A, x, M, K, w, b, N, **kw):
+    out = A(M, N)
+    gemm_ex(x, w, out, M, N, K, K, K, N, bias=b, **kw)
+    return out
+
+
+def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w):
+    cfg, w = model.cfg, model._packed
+    dev = frames.device
+    T, _, H0, W0 = frames.shape
+    ar = model._get_arena(T, H0, W0, dev)
+    ar.reset()
+    A = ar.alloc
+    sc = model._shape_consts(T, H0, W0, dev)
+    sizes, lvl_sizes, S, starts = sc["sizes"], sc["lvl_sizes"], sc["S"], sc["starts"]
+    Q = cfg.num_queries
+    ff = cfg.dim_feedforward
+
+    # ------------------------------------------------------------------ backbone
+    feats = _swin_backbone(model, frames, ar, sizes)
+
+    # ------------------------------------------------------------------ text (FeatureResizer :616-635)
+    L = text_hidden.shape[0]
+    tmp = _lin(A, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+    text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=A(L, D))
+    tmp = _lin(A, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+    sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=A(1, D))
+    text_pos = model._text_pos(L, dev)
+
+    def text_kv(pre):
+        k = A(L, D)
+        gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
+        v = _lin(A, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
+        return k, v
+
+    # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
+    src = A(T * S, D)  # [T, S, 256]: the encoder sequence
+    fk, fv = text_kv("fusion_module.multihead_attn.")
+    chs = cfg.num_channels
+    for l in range(4):
+        h, ww = lvl_sizes[l]
+        hw = h * ww
+        m0 = ar.mark()
+        if l < 3:
+            s = _lin(A, feats[1 + l], T * hw, chs[1 + l], w[f"input_proj.{l}.0.weight"], w[f"input_proj.{l}.0.bias"], D)
+        else:
+            h5, w5 = sizes[3]
+            s, ho, wo = ops.conv2d_cl(feats[3], w["input_proj.3.0.weight:cl"], T, h5, w5, chs[3], 3, 3, 2, 1,
+                                      bias=w["input_proj.3.0.bias"], alloc=A)
+            assert (ho, wo) == (h, ww)
+        s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
+        q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
+        att = A(T * hw, D)
+        ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+        # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
+        gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
+                bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
+                sA=hw * D, sC=S * D, sRes=hw * D)
+        ar.release(m0)
+
+    # ------------------------------------------------------------------ encoder (:611-627)
+    lvl_pos, enc_ref = sc["lvl_pos"], sc["enc_ref"]
+    Fk = cfg.f_token
+    if Fk > 0:
+        token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
+        tpos = w["transformer.encoder.memory_pos"]
+
+    def ffn(x, M, pre, l1="linear1", l2="linear2"):
+        """x <- x + W2 relu(W1 x) (in place)."""
+        m1 = ar.mark()
+        hdn = A(M, ff)
+        gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
+        gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
+                res_mode=RES_ADD)
+        ar.release(m1)
+
+    def ln_(x, pre):
+        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
+
+    def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid):
+        """resid <- resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src))).  query [T*q_per_frame, D]."""
+        m1 = ar.mark()
+        value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
+        proj = A(q_rows, 384)
+        if q_pos_shared:  # position map shared by all frames: frame-batched launch, stride 0 on the addend
+            gemm_ex(query, w[pre + "offaw.weight"], proj, q_per_frame, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
+                    a2=q_pos, lda2=D, batch=T, sA=q_per_frame * D, sA2=0, sC=q_per_frame * 384)
+        else:
+            gemm_ex(query, w[pre + "offaw.weight"], proj, q_rows, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
+                    a2=q_pos, lda2=D)
+        samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
+                              out=A(q_rows, D))
+        gemm_ex(samp, w[pre + "output_proj.weight"], resid, q_rows, D, D, D, D, D, bias=w[pre + "output_proj.bias"],
+                res=resid, ldres=D, res_mode=RES_ADD)
+        ar.release(m1)
+
+    for i in range(cfg.enc_layers):
+        lp = f"transformer.encoder.layers.{i}."
+        if Fk > 0:
+            fp = lp + "ftoken_layers."
+            m0 = ar.mark()
+            # (1) tokens gather from their frame by MSDA (:447-454)
+            r = _lin(A, token, T * Fk, D, w[fp + "reference_points.weight"], w[fp + "reference_points.bias"], 2)
+            ref = ops.sigmoid(r, out=A(T * Fk, 2))
+            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, ref, 2, True, token)
+            ln_(token, fp + "norm1")
+            # (2) all T*F tokens attend to each other (:463-469)
+            pre = fp + "token_self_atten."
+            qk = A(T * Fk, 2 * D)
+            gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
+                    batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
+            v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(T * Fk, D)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, T * Fk, T * Fk, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+            gemm_ex(att, w[pre + "out_proj.weight"], token, T * Fk, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
+                    res=token, ldres=D, res_mode=RES_ADD)
+            ln_(token, fp + "norm2")
+            # (3) every pixel attends to the F tokens of its own frame (:480-484)
+            pre = fp + "frame_token_atten."
+            q = A(T * S, D)
+            gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
+                    sA=S * D, sA2=0, sC=S * D)
+            k = A(T * Fk, D)
+            gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
+                    sA=Fk * D, sA2=0, sC=Fk * D)
+            v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(T * S, D)
+            ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
+            gemm_ex(att, w[pre + "out_proj.weight"], src, T * S, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=src,
+                    ldres=D, res_mode=RES_ADD)
+            ln_(src, fp + "norm3")
+            ar.release(m0)
+            # (4) FFN over all pixels (:489-491)
+            ffn(src, T * S, fp)
+            ln_(src, fp + "norm4")
+        msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src)
+        ln_(src, lp + "norm1")
+        ffn(src, T * S, lp)
+        ln_(src, lp + "norm2")
+    memory = src
+
+    # ------------------------------------------------------------------ decoder (:721-790)
+    nl = cfg.dec_layers
+    hs = A(nl, T * Q, D)
+    inter_ref = A(nl, T * Q, 4)
+    qpos = w["query_embed.weight"]  # [Q, D], shared by all frames
+    r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
+    init_ref = ops.tile(ops.sigmoid(r, out=A(Q, 2)), T, out=A(T * Q, 2))
+    tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
+    ref, ref_dim = init_ref, 2
+    for lid in range(nl):
+        lp = f"transformer.decoder.layers.{lid}."
+        m0 = ar.mark()
+        pre = lp + "self_attn."
+        qk = A(T * Q, 2 * D)
+        gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
+                sA=Q * D, sA2=0, sC=Q * 2 * D)
+        v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
+        att = A(T * Q, D)
+        if cfg.qtrans:
+            # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
+            ops.mha_core(qk, qk[:, D:], v, Q, NH, T, T, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att, Q * D, D)
+        else:
+            ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
+        gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                ldres=D, res_mode=RES_ADD)
+        ln_(tgt, lp + "norm2")
+        msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt)
+        ln_(tgt, lp + "norm1")
+        ffn(tgt, T * Q, lp)
+        ln_(tgt, lp + "norm3")
+        if cfg.with_box_refine:
+            bp = f"bbox_embed.{lid}.layers."
+            t1 = A(T * Q, D)
+            gemm_ex(tgt, w[bp + "0.weight"], t1, T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
+            t2 = A(T * Q, D)
+            gemm_ex(t1, w[bp + "1.weight"], t2, T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
+            t3 = _lin(A, t2, T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
+            ops.box_refine(t3, ref, out=inter_ref[lid])
+            ref, ref_dim = inter_ref[lid], 4
+        ar.release(m0)
+        ops.tile(tgt, 1, out=hs[lid])
+        if not cfg.with_box_refine:
+            raise NotImplementedError("with_box_refine=False: decoder references stay 2-d; not wired yet")
+
+    # ------------------------------------------------------------------ heads (:330-365)
+    # with box refinement bbox_embed[l] IS transformer.decoder.bbox_embed[l] (tce_rvos.py:124), so
+    # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(ref_{l-1})) is exactly inter_ref[l].
+    logits = A(nl, T * Q, cfg.num_classes)
+    for lvl in range(nl):
+        gemm_ex(hs[lvl], w[f"class_embed.{lvl}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
+                bias=w[f"class_embed.{lvl}.bias"])
+
+    # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_)
+
+    # ------------------------------------------------------------------ dynamic mask head (:371-380, 426-510)
+    h4, w4 = sizes[0]
+    npar = cfg.num_gen_params
+    m0 = ar.mark()
+    c1 = A(nl * T * Q, D)
+    gemm_ex(hs, w["controller.layers.0.weight"], c1, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.0.bias"],
+            act=ACT_RELU)
+    c2 = A(nl * T * Q, D)
+    gemm_ex(c1, w["controller.layers.1.weight"], c2, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.1.bias"],
+            act=ACT_RELU)
+    params = _lin(A, c2, nl * T * Q, D, w["controller.layers.2.weight"], w["controller.layers.2.bias"], npar)
+    w0f = A(T, nl * Q * 8, cfg.mask_dim)
+    tail = A(nl, T * Q, 112)
+    ops.mask_pack(params, nl, T, Q, cfg.mask_dim, w0f, tail)
+    G = A(T, h4 * w4, nl * Q * 8)
+    ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
+    masks = A(nl, T, Q, h4, w4)
+    ops.mask_tail(G, tail, inter_ref, 4, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
+
+    # ------------------------------------------------------------------ output dict (:360-393); leave the arena
+    K = cfg.num_classes
+    out = {
+        "pred_logits": logits[-1].reshape(1, T, Q, K).clone(),
+        "pred_boxes": inter_ref[-1].reshape(1, T, Q, 4).clone(),
+        "pred_masks": masks[-1].reshape(1, T, Q, h4, w4).clone(),
+    }
+    if cfg.aux_loss:
+        out["aux_outputs"] = [{"pred_logits": logits[i].reshape(1, T, Q, K).clone(),
+                               "pred_boxes": inter_ref[i].reshape(1, T, Q, 4).clone(),
+                               "pred_masks": masks[i].reshape(1, T, Q, h4, w4).clone()} for i in range(nl - 1)]
+    if not model.training:
+        out["reference_points"] = inter_ref[-2].reshape(1, T, Q, 4)[..., :2].clone()
+    out["memory"] = memory.reshape(T, S, D).clone()
+    ar.release(m0)
+    return out
+
+
+def _swin_backbone(model, frames, ar, sizes):
+    """swin_transformer.py:595-617: returns the four normed stage maps, token-major [T*h*w, C_i].
+    Video-Swin (video_swin_transformer.py:678-697): same program with the 3-D window kernel, the (1,4,4) patch
+    conv applied per frame, stage outputs taken before the merge and WITHOUT an output norm."""
+    cfg, w = model.cfg, model._packed
+    A = ar.alloc
+    T = frames.shape[0]
+    b = "backbone.0.body."
+    C = cfg.embed_dim
+    (H, W) = sizes[0]
+    x = A(T * H * W, C)
+    ops.patch_embed(frames, w[b + ("patch_embed.proj.weight:2d" if cfg.video else "patch_embed.proj.weight")],
+                    w[b + "patch_embed.proj.bias"],
+                    w[b + "patch_embed.norm.weight"], w[b + "patch_embed.norm.bias"], out=x)
+    feats = []
+    for i, depth in enumerate(cfg.depths):
+        H, W = sizes[i]
+        ntok = T * H * W
+        nH = cfg.num_heads[i]
+        out_i = None if cfg.video else A(ntok, C)
+        x_next = None
+        if i < len(cfg.depths) - 1:
+            H2, W2 = sizes[i + 1]
+            x_next = A(T * H2 * W2, 2 * C)
+        hid = int(C * cfg.mlp_ratio)
+        for j in range(depth):
+            p = f"{b}layers.{i}.blocks.{j}."
+            m0 = ar.mark()
+            xn = ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=A(ntok, C))
+            qkv = A(ntok, 3 * C)
+            gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
+            if cfg.video:
+                att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
+                                        W, C, nH, j % 2 == 1, out=xn)
+            else:
+                att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
+                                      C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
+            gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
+                    res_mode=RES_ADD)
+            ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
+            hdn = A(ntok, hid)
+            gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"], act=ACT_GELU)
+            gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
+                    ldres=C, res_mode=RES_ADD)
+            ar.release(m0)
+        if cfg.video:
+            feats.append(x)
+        else:
+            ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i)
+            feats.append(out_i)
+        if x_next is not None:
+            m0 = ar.mark()
+            p = f"{b}downsamples.{i}." if cfg.video else f"{b}layers.{i}.downsample."
+            xm, _, _ = ops.patch_merge_ln(x, w[p + "norm.weight"], w[p + "norm.bias"], T, H, W, C, alloc=A)
+            gemm_ex(xm, w[p + "reduction.weight"], x_next, x_next.shape[0], 2 * C, 4 * C, 4 * C, 4 * C, 2 * C)
+            ar.release(m0)
+            x = x_next
+            C *= 2
+    return feats
+
+
+def _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_):
+    """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level."""
+    cfg, w = model.cfg, model._packed
+    A = ar.alloc
+    sizes, S, starts = sc["sizes"], sc["S"], sc["starts"]
+    pd = "pixel_decoder."
+    y = None
+    y_hw = None
+    out_final = None
+    for stage in (4, 3, 2, 1):
+        h, ww = sizes[stage - 1]
+        hw = h * ww
+        pos = sc["pos"][stage - 1]  # [hw, 256] backbone-level sine map (no level embedding)
+        y_new = A(T * hw, D)
+        m0 = ar.mark()
+        # lateral 1x1 conv (no bias) + GN(8)
+        vis = A(T * hw, D)
+        if stage > 1:
+            l = stage - 2  # encoder level index: stage 4 <-> level 2 (32x)
+            gemm_ex(memory[starts[l]:], w[f"{pd}adapter_{stage}.weight"], vis, hw, D, D, D, D, D, batch=T, sA=S * D,
+                    sC=hw * D)
+        else:
+            c0 = cfg.num_channels[0]
+            gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
+        tgt = ops.groupnorm_cl(vis, w[f"{pd}adapter_{stage}.norm.weight"], w[f"{pd}adapter_{stage}.norm.bias"], T, hw, D, 8,
+                               out=vis, alloc=A)
+        if cfg.vlblock:
+            bp = f"{pd}cross_attn_{stage}."
+            pre = bp + "self_attn."
+            red = sc["red"].get(stage)
+            m1 = ar.mark()
+            if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
+                nh_, nw_, pos_low = red
+                n_low = T * nh_ * nw_
+                x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
+                qk = A(n_low, 2 * D)
+                gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
+                        lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
+                v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                att = A(n_low, D)
+                ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+                o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
+                ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
+            else:
+                n = T * hw
+                qk = A(n, 2 * D)
+                gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
+                        batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
+                v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                att = A(n, D)
+                ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+                gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                        ldres=D, res_mode=RES_ADD)
+            ar.release(m1)
+            ln_(tgt, bp + "norm1")
+            # text cross-attention (:366-371)
+            pre = bp + "multihead_attn."
+            m1 = ar.mark()
+            tk, tv = text_kv(pre)
+            q = A(T * hw, D)
+            gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
+                    sA2=0, sC=hw * D)
+            att = A(T * hw, D)
+            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * hw, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                    ldres=D, res_mode=RES_ADD)
+            ar.release(m1)
+            ln_(tgt, bp + "norm2")
+            ffn(tgt, T * hw, bp)
+            ln_(tgt, bp + "norm3")
+        # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
+        if y is not None:
+            ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
+        conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=A)
+        ops.groupnorm_cl(conv, w[f"{pd}layer_{stage}.norm.weight"], w[f"{pd}layer_{stage}.norm.bias"], T, hw, D, 8,
+                         relu=True, out=y_new, alloc=A)
+        ar.release(m0)
+        y, y_hw = y_new, (h, ww)
+    h, ww = sizes[0]
+    out_final, _, _ = ops.conv2d_cl(y, w[pd + "mask_features.weight:cl"], T, h, ww, D, 3, 3, 1, 1,
+                                    bias=w[pd + "mask_features.bias"], alloc=A)
+    return out_final

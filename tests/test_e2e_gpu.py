@@ -1,0 +1,117 @@
+"""GPU: the full HIP per-clip forward (through build_model / forward) against
+  (a) outputs of the REFERENCE itself (tests/golden/e2e_*.npz) and
+  (b) the CPU oracle on the same seeded inputs and weights.
+Tolerance: the north star asks for masks within 1e-3 IoU of the reference; we additionally bound the
+max-abs logit error (fp32 everywhere; differences come only from summation order)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tce_oracle as O  # noqa: E402
+from _util import load_npz, synth_frames  # noqa: E402
+
+
+def _args(backbone):
+    return argparse.Namespace(backbone=backbone, with_box_refine=True, binary=True, freeze_text_encoder=True, f_token=8,
+                              qtrans=True, num_feature_levels=4, text_encoder_layers=1)
+
+
+@pytest.fixture(scope="module")
+def models():
+    cache = {}
+
+    def get(backbone, salt):
+        from tce_rvos_amd import build_model, load_synth_weights
+        key = backbone
+        if key not in cache:
+            m, _, _ = build_model(_args(backbone))
+            cache[key] = m.cuda().eval()
+        m = cache[key]
+        load_synth_weights(m, salt)
+        m.repack()
+        return m
+    return get
+
+
+def _compare(out, fx, atol_mask, prefix="out_"):
+    res = {}
+    for k in ("pred_logits", "pred_boxes", "reference_points", "pred_masks"):
+        ref = torch.from_numpy(fx[prefix + k])
+        res[k] = (out[k].cpu() - ref).abs().max().item()
+    print("max abs diffs vs reference:", res)
+    assert res["pred_logits"] < 2e-3 and res["pred_boxes"] < 1e-4 and res["reference_points"] < 1e-4
+    assert res["pred_masks"] < atol_mask
+    a = out["pred_masks"].cpu()[0] > 0
+    b = torch.from_numpy(fx[prefix + "pred_masks"])[0] > 0
+    iou = O.mask_iou(a, b)
+    print("all-query mask IoU vs reference:", iou)
+    assert iou > 1 - 1e-3
+    mem = out["memory"].double().abs().sum().item()
+    assert abs(mem - float(fx["out_memory_abs_sum"])) / float(fx["out_memory_abs_sum"]) < 1e-5
+
+
+def _run(models, fixture, backbone):
+    fx = load_npz(fixture)
+    T, H, W = (int(v) for v in fx["thw"])
+    model = models(backbone, int(fx["weights_salt"]))
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    out = model.forward_features(frames, torch.from_numpy(fx["text_hidden"])[0].cuda(),
+                                 torch.from_numpy(fx["text_pooled"])[0].cuda(), float(H), float(W))
+    torch.cuda.synchronize()
+    return fx, out, model
+
+
+def test_swin_t_small_matches_reference(models):
+    fx, out, _ = _run(models, "e2e_swin_t_small.npz", "swin_t_p4w7")
+    _compare(out, fx, 5e-3)
+    assert (out["memory"].cpu() - torch.from_numpy(fx["out_memory"])).abs().max().item() < 1e-3
+    for i in range(3):
+        d = (out["aux_outputs"][i]["pred_masks"].cpu() - torch.from_numpy(fx[f"aux{i}_pred_masks"])).abs().max().item()
+        assert d < 5e-3, (i, d)
+
+
+def test_swin_t_config2_fullsize_matches_reference(models):
+    """BASELINE config 2: T=5, 360x640, Swin-T."""
+    fx, out, _ = _run(models, "e2e_swin_t_cfg2.npz", "swin_t_p4w7")
+    _compare(out, fx, 2e-2)
+
+
+def test_forward_boundary_matches_oracle_and_is_deterministic(models):
+    """Through model(samples, captions, targets) with token ids; second call must be bit-identical
+    (the arena / cached constants must not leak state between clips)."""
+    model = models("swin_t_p4w7", 7)
+    T, H, W = 4, 96, 132
+    frames = synth_frames(T, H, W, 99)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 50000, (1, 11), generator=g)
+    ids[0, 0], ids[0, -1] = 0, 2
+    tgt = [{"size": torch.tensor([H, W])}]
+    out1 = model([frames.cuda()], ids, tgt)
+    other = model([synth_frames(2, 64, 64, 3).cuda()], ids, [{"size": torch.tensor([64, 64])}])  # different shape in between
+    out2 = model([frames.cuda()], ids, tgt)
+    torch.cuda.synchronize()
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "memory"):
+        assert torch.equal(out1[k], out2[k]), k
+    hid, pooled = model.forward_text_encoder(ids, "cuda")
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = O.forward(sd, O.OracleConfig(), frames, hid.cpu(), pooled.cpu(), img_size=(H, W))
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("pred_masks", 5e-3), ("reference_points", 1e-4)):
+        d = (out1[k].cpu() - ref[k]).abs().max().item()
+        assert d < tol, (k, d)
+    assert O.mask_iou(out1["pred_masks"].cpu() > 0, ref["pred_masks"] > 0) > 1 - 1e-3
+    # caller harness H on both sides (inference_ytvos.py:238-250)
+    ma, qa = O.select_masks(out1["pred_logits"].cpu()[0], out1["pred_masks"].cpu()[0], (H, W))
+    mb, qb = O.select_masks(ref["pred_logits"][0], ref["pred_masks"][0], (H, W))
+    assert qa == qb and O.mask_iou(ma, mb) > 1 - 1e-3
+    assert set(out1) == {"pred_logits", "pred_boxes", "pred_masks", "aux_outputs", "reference_points", "memory"}
+    assert tuple(out1["pred_masks"].shape) == (1, T, 5, 24, 33) and tuple(out1["memory"].shape)[0] == T
+
+
+def test_video_swin_t_small_matches_reference(models):
+    """Video-Swin-T backbone, T=9 (> window depth 8: temporal padding + temporal shift path)."""
+    fx, out, _ = _run(models, "e2e_vswin_t_small.npz", "video_swin_t_p4w7")
+    _compare(out, fx, 5e-3)

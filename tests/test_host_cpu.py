@@ -1,0 +1,114 @@
+"""CPU: host logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as g
+    from tce_rvos_amd import build as b
+    return b.build(verbose=False)
+
+
+def test_header_symbols_all_exported_and_bound(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "tce_rvos.h")).read()
+    declared = set(re.findall(r"\b(tce_[a-z0-9_]+)\s*\(", hdr))
+    from tce_rvos_amd import _lib
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    l = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(l, name), name
+    assert _lib.lib().tce_abi_version() == 1
+
+
+def test_bad_arguments_are_rejected_with_a_message(built_lib):
+    from tce_rvos_amd import _lib
+    l = _lib.lib()
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K = 4, 4, 7  # K not a multiple of 16, null pointers
+    assert l.tce_gemm_f32(ctypes.byref(g), None) != 0
+    assert b"tce_gemm_f32" in l.tce_last_error()
+    assert l.tce_layernorm_f32(None, None, None, None, None, 1, 4, 1e-5, None) != 0
+    assert l.tce_msda_fused_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 2, 0, None) != 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from tce_rvos_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtce_rvos.so")
+    with pytest.raises(_lib.TceError):
+        _lib.lib()
+
+
+@pytest.mark.parametrize("bb,man", [("swin_t_p4w7", "statedict_swin_t.json"), ("video_swin_t_p4w7", "statedict_vswin_t.json")])
+def test_param_manifest_matches_reference_state_dict(bb, man):
+    from tce_rvos_amd.config import BACKBONES, ModelConfig, index_buffers, param_shapes
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", man)))
+    b = BACKBONES[bb]
+    cfg = ModelConfig(backbone=bb, video=b["video"], embed_dim=b["embed_dim"], depths=b["depths"], num_heads=b["num_heads"])
+    mine = dict(param_shapes(cfg))
+    mine.update(index_buffers(cfg))
+    for k in list(mine):
+        if k.startswith("bbox_embed."):
+            mine["transformer.decoder." + k] = mine[k]
+    assert set(mine) == set(ref)
+    for k, (shape, dtype) in ref.items():
+        assert tuple(shape) == tuple(mine[k]), k
+
+
+def test_model_state_dict_contract_and_build_model_boundary():
+    import argparse
+    import transformers
+    from tce_rvos_amd import build_model
+    from tce_rvos_amd.model import ReferFormer
+    args = argparse.Namespace(backbone="swin_t_p4w7", with_box_refine=True, binary=True, freeze_text_encoder=True,
+                              f_token=8, qtrans=True, num_feature_levels=4, text_encoder_layers=1)
+    model, criterion, post = build_model(args)
+    assert isinstance(model, ReferFormer)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "statedict_swin_t.json")))
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    assert set(sd) == set(ref)
+    for k, (shape, dtype) in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape) and str(sd[k].dtype).endswith(dtype), k
+    # aliasing of the refinement heads (tce_rvos.py:124)
+    assert model.transformer.decoder.bbox_embed is model.bbox_embed
+    # the reference callers' attribute accesses (main.py:60,63)
+    assert model.backbone is not None and model.transformer.encoder is not None
+    # strict=False round trip like inference_ytvos.py:150-157
+    missing, unexpected = model.load_state_dict({k: v for k, v in model.state_dict().items()}, strict=False)
+    assert not missing and not unexpected
+    assert all(not p.requires_grad for p in model.text_encoder.parameters())
+    with pytest.raises(Exception):
+        model([torch.zeros(2, 3, 32, 32)], ["a"], [{"size": torch.tensor([32, 32])}])  # CPU input: no CPU path
+
+
+def test_unsupported_configs_fail_loudly():
+    import argparse
+    from tce_rvos_amd import build_model
+    with pytest.raises(ValueError):
+        build_model(argparse.Namespace(backbone="resnet50"))
+    with pytest.raises(AssertionError):
+        build_model(argparse.Namespace(backbone="swin_t_p4w7", two_stage=True))
+
+
+def test_synth_weights_are_deterministic_and_alias_safe():
+    from tce_rvos_amd.weights import synth_tensor
+    a = synth_tensor("transformer.decoder.bbox_embed.1.layers.0.weight", (4, 4))
+    b = synth_tensor("bbox_embed.1.layers.0.weight", (4, 4))
+    assert torch.equal(a, b)
+    assert not torch.equal(synth_tensor("x.weight", (4, 4), 0), synth_tensor("x.weight", (4, 4), 1))
+
+
+def test_nested_tensor_from_videos_list():
+    from tce_rvos_amd import nested_tensor_from_videos_list
+    nt = nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6), torch.ones(3, 3, 5, 5)])
+    assert tuple(nt.tensors.shape) == (2, 3, 3, 5, 6) and tuple(nt.mask.shape) == (2, 3, 5, 6)
+    assert not nt.mask[0, :2, :4, :6].any() and nt.mask[0, 2].all() and nt.mask[1, :, :, 5].all()

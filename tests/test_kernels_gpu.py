@@ -288,3 +288,36 @@ def test_dynamic_mask_head(ops):
     masks = torch.empty(nl, T, Q, h, w, device="cuda")
     ops.mask_tail(G, tail, dev(refs), 4, masks, nl, T, Q, h, w, img[0], img[1])
     close(masks.view(nl, T * Q, h, w), expect, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("T,H,W,nH,shifted", [(3, 18, 25, 3, False), (3, 18, 25, 3, True), (9, 9, 13, 2, True),
+                                               (9, 3, 4, 2, True), (8, 7, 7, 1, True), (17, 8, 6, 1, True)])
+def test_window_attention_3d(ops, T, H, W, nH, shifted):
+    """3-D window attention core against the oracle's Video-Swin block internals (which are pinned to the
+    reference by e2e_vswin_t_small.npz)."""
+    g = torch.Generator().manual_seed(T * H + W)
+    C = nH * 32
+    x = torch.randn(1, T, H, W, C, generator=g)  # stands for norm1(x)
+    sd = {"attn.qkv.weight": torch.randn(3 * C, C, generator=g) / math.sqrt(C),
+          "attn.qkv.bias": torch.randn(3 * C, generator=g) * 0.3,
+          "attn.relative_position_bias_table": torch.randn(15 * 13 * 13, nH, generator=g),
+          "attn.proj.weight": torch.eye(C), "attn.proj.bias": torch.zeros(C)}
+    full = (8, 7, 7)
+    ws, ss = O.get_window_size_3d((T, H, W), full, tuple(i // 2 for i in full) if shifted else (0, 0, 0))
+    pd, pb, pr = (ws[0] - T % ws[0]) % ws[0], (ws[1] - H % ws[1]) % ws[1], (ws[2] - W % ws[2]) % ws[2]
+    xx = F.pad(x, (0, 0, 0, pr, 0, pb, 0, pd))
+    Dp, Hp, Wp = T + pd, H + pb, W + pr
+    am = None
+    if any(i > 0 for i in ss):
+        xx = torch.roll(xx, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+        am = O.compute_mask_3d(Dp, Hp, Wp, ws, ss)
+    xw = O.window_partition_3d(xx, ws)
+    aw = O.window_attention_3d(sd, "attn.", xw, nH, full, am)
+    y = O.window_reverse_3d(aw, ws, 1, Dp, Hp, Wp)
+    if any(i > 0 for i in ss):
+        y = torch.roll(y, shifts=(ss[0], ss[1], ss[2]), dims=(1, 2, 3))
+    ref = y[:, :T, :H, :W].reshape(T * H * W, C)
+    qkv = F.linear(x, sd["attn.qkv.weight"], sd["attn.qkv.bias"]).reshape(T * H * W, 3 * C)
+    out = ops.window_attn3d(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
+                            C, nH, shifted)
+    close(out, ref, 1e-4, 1e-4)
