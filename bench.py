@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the north-star path: per-clip forward of TCE-RVOS on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one B=1 clip forward on every rank: Swin-T backbone, T=5 frames of 360x640, a 32-token text
+(RoBERTa-base, random init, evaluated every step as the reference does), FTF/IQT deformable transformer,
+cross-modal FPN, dynamic mask head -- BASELINE.json config 2 -- followed (N > 1) by the RCCL all-gather of the
+per-clip mask logits.  Clips are independent units sharded over ranks (weak scaling, no data-path collective
+besides the gather).  Inputs and weights are synthetic and already resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     : the dominant kernel (fp32 MFMA GEMM, 128x128 tile) -- algorithmic FLOPs of its launches in one
+                 step / their summed launch durations, measured with events on the launch stream in a second,
+                 instrumented pass over the same K steps (the headline `value` comes from the un-instrumented pass).
+  cpu_baseline : the CPU oracle (a port of the reference path) timed on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--tokens", type=int, default=32)
+    ap.add_argument("--backbone", default="swin_t_p4w7")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tce_rvos_amd import build_model, ops
+
+    margs = argparse.Namespace(backbone=args.backbone, with_box_refine=True, binary=True, freeze_text_encoder=True,
+                               f_token=8, qtrans=True, num_feature_levels=4)
+    model, _, _ = build_model(margs)
+    model = model.to(dev).eval()
+
+    T, H, W = args.frames, args.height, args.width
+    g = torch.Generator().manual_seed(1234 + rank)
+    n_pool = 4
+    clips = [torch.randn(T, 3, H, W, generator=g).to(dev) for _ in range(n_pool)]
+    ids = torch.randint(3, 50264, (n_pool, 1, args.tokens), generator=g)
+    ids[:, :, 0], ids[:, :, -1] = 0, 2
+    ids = ids.to(dev)
+    targets = [{"size": torch.tensor([H, W])}]
+    gather_buf = None
+
+    def step(i):
+        nonlocal gather_buf
+        out = model([clips[i % n_pool]], ids[i % n_pool], targets)
+        if world > 1:
+            m = out["pred_masks"]
+            if gather_buf is None:
+                gather_buf = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device=dev)
+            dist.all_gather_into_tensor(gather_buf, m.contiguous())
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        ops.GEMM_PROFILE = []
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        agg = {}
+        for tile, conv, flops, e0, e1 in prof:
+            a = agg.setdefault((tile, conv), [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        key = max(agg, key=lambda k: agg[k][1])
+        fl, sec, n = agg[key]
+        peak = 157.3
+        ach = fl / sec / 1e12
+        gemm_sec_per_step = sum(v[1] for v in agg.values()) / args.steps
+        tname = {128128: "128,128", 12864: "128,64", 6464: "64,64"}[key[0]]
+        roofline = {"bound": "mfma", "kernel": f"gemm_f32_kernel<{tname},{'true' if key[1] else 'false'}>",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches_per_step": n // args.steps,
+                    "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
+                    "all_gemm_ms_per_step": round(gemm_sec_per_step * 1e3, 3),
+                    "all_gemm_tflops": round(sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12, 2)}
+
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import tce_oracle as O
+        cores = torch.get_num_threads()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+        frames_cpu = clips[0].cpu()
+        with torch.no_grad():
+            hid, pooled = model.forward_text_encoder(ids[0], dev)
+            hid, pooled = hid.cpu(), pooled.cpu()
+            cfg = O.OracleConfig(backbone=args.backbone)
+            times = []
+            for _ in range(2):
+                t1 = time.perf_counter()
+                ref = O.forward(sd, cfg, frames_cpu, hid, pooled, img_size=(H, W))
+                times.append(time.perf_counter() - t1)
+        cpu_baseline = {"value": round(1.0 / times[-1], 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                        "sample": f"1 clip (T={T}, {H}x{W}, {args.tokens} tokens), 2nd of 2 oracle forwards, "
+                                  f"{times[-1]:.2f} s; text encoder excluded"}
+        out = step(0)
+        torch.cuda.synchronize()
+        pm = out["pred_masks"].cpu()
+        parity = {"mask_iou_vs_oracle": round(O.mask_iou(pm > 0, ref["pred_masks"] > 0), 6),
+                  "max_abs_logit_err": float((pm - ref["pred_masks"]).abs().max())}
+
+    if rank == 0:
+        clips_total = args.steps * world
+        line = {"metric": METRIC, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
+                                       f"flags --with_box_refine --binary --f_token 8 --qtrans (BASELINE config 2)",
+                           "clips_per_step": world, "parallelism": f"clip-sharded x{world}" +
+                                                                   (" + RCCL all_gather(pred_masks)" if world > 1 else "")},
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

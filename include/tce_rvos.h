@@ -50,6 +50,8 @@ typedef struct {
   int32_t T, H, Wd, Cin, Ho, Wo, kh, kw, stride, pad;
 } tceGemmArgs;
 int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
+/* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
+int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
 
 /* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
  * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */

@@ -200,6 +200,17 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
+// (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
+extern "C" int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch) {
+  const long long b = batch > 0 ? batch : 1;
+  const long long n128 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 128) * b;
+  const long long n12864 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 64) * b;
+  if (n128 >= 512 && N > 64) return 128128;
+  if (n12864 >= 384 && M > 64) return 12864;
+  return 6464;
+}
+
 extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   TCE_CHECK_ARG(args != nullptr, "tce_gemm_f32: null args");
   tceGemmArgs a = *args;
@@ -225,13 +236,9 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
     TCE_CHECK_ARG(!a.A2 || (a.lda2 % 4 == 0 && a.lda2 >= a.K), "tce_gemm_f32: lda2 invalid");
   }
   hipStream_t s = (hipStream_t)stream;
-  // tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
-  // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
-  const long long b = a.batch;
-  const long long n128 = (long long)tce_cdiv(a.M, 128) * tce_cdiv(a.N, 128) * b;
-  const long long n12864 = (long long)tce_cdiv(a.M, 128) * tce_cdiv(a.N, 64) * b;
-  if (n128 >= 512 && a.N > 64) launch<128, 128>(a, s);
-  else if (n12864 >= 384 && a.M > 64) launch<128, 64>(a, s);
+  const int tile = tce_gemm_select_tile(a.M, a.N, a.batch);
+  if (tile == 128128) launch<128, 128>(a, s);
+  else if (tile == 12864) launch<128, 64>(a, s);
   else launch<64, 64>(a, s);
   TCE_CHECK_LAUNCH("tce_gemm_f32");
   return TCE_OK;

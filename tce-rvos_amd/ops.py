@@ -45,6 +45,23 @@ class Arena:
         return self.buf[start:end].view(dtype).view(*[int(s) for s in shape])
 
 
+# When set to a list, every GEMM launch is bracketed by events on the launch stream and
+# (tile, flops, start_event, end_event) is appended: bench.py's live roofline measurement.
+GEMM_PROFILE = None
+
+
+def _gemm_launch(g):
+    if GEMM_PROFILE is None:
+        check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+    e1.record()
+    b = max(1, g.batch)
+    GEMM_PROFILE.append((lib().tce_gemm_select_tile(g.M, g.N, b), bool(g.conv), 2.0 * g.M * g.N * g.K * b, e0, e1))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -94,7 +111,7 @@ def gemm(a, w, bias=None, a2=None, act=ACT_NONE, res=None, res_mode=RES_NONE, ou
             raise ValueError("gemm: res shape mismatch")
         g.res, g.ldres = rp, ldr
     g.act, g.res_mode, g.batch = act, res_mode, 1
-    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+    _gemm_launch(g)
     return out
 
 
@@ -115,7 +132,7 @@ def gemm_batched(a, w, out, bias=None, act=ACT_NONE):
     if bias is not None:
         g.bias, g.sBias = bias.data_ptr(), N
     g.act = act
-    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32(batched)")
+    _gemm_launch(g)
     return out
 
 
@@ -139,7 +156,7 @@ def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT
     g.act, g.batch, g.conv = act, 1, 1
     g.T, g.H, g.Wd, g.Cin, g.Ho, g.Wo = T, H, W, Cin, Ho, Wo
     g.kh, g.kw, g.stride, g.pad = kh, kw, stride, pad
-    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32(conv)")
+    _gemm_launch(g)
     return out, Ho, Wo
 
 
@@ -336,5 +353,5 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
         g.res, g.ldres = res.data_ptr(), ldres
     g.act, g.res_mode, g.batch = act, res_mode, batch
     g.sA, g.sA2, g.sW, g.sBias, g.sC, g.sRes = sA, sA2, sW, sBias, sC, sRes
-    check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
+    _gemm_launch(g)
     return out
