@@ -58,6 +58,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from tce_rvos_amd import build_model, ops
+    from tce_rvos_amd.dist import gather_clip_masks
 
     margs = argparse.Namespace(backbone=args.backbone, with_box_refine=True, binary=True, freeze_text_encoder=True,
                                f_token=8, qtrans=True, num_feature_levels=4)
@@ -77,11 +78,8 @@ def main():
     def step(i):
         nonlocal gather_buf
         out = model([clips[i % n_pool]], ids[i % n_pool], targets)
-        if world > 1:
-            m = out["pred_masks"]
-            if gather_buf is None:
-                gather_buf = torch.empty((world,) + tuple(m.shape), dtype=m.dtype, device=dev)
-            dist.all_gather_into_tensor(gather_buf, m.contiguous())
+        if world > 1:  # one clip per rank per step; the masks of all `world` clips meet on every rank
+            gather_buf = gather_clip_masks(out["pred_masks"], world)
         return out
 
     def fence():
@@ -131,7 +129,8 @@ def main():
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tce_oracle as O
-        cores = torch.get_num_threads()
+        cores = min(32, os.cpu_count() or 1)  # oneDNN/MKL scale poorly past ~32 threads on this graph
+        torch.set_num_threads(cores)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
         frames_cpu = clips[0].cpu()
         with torch.no_grad():

@@ -1,0 +1,56 @@
+"""Clip sharding over the GPUs of one node.
+
+Clips are independent units (the reference shards videos over processes with no communication,
+inference_ytvos.py:96-113); here each rank (one process per GPU) runs B=1 forwards on its contiguous block of
+clips and the per-clip mask logits meet through ONE collective per batch: an all-gather over RCCL/xGMI
+(`torch.distributed` backend "nccl" on ROCm).  No other data-path collective exists on this path.
+The same code runs on the gloo backend (CPU tensors) for the world_size-2 tests.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one item, earlier ranks get the extras."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_clip_masks(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """local [n_local, ...] (this rank's clips, in clip order) -> [n_total, ...] on every rank, in global clip order.
+    Ranks may hold different clip counts (n_total % world != 0): shards are padded to the largest count for the
+    collective and trimmed after."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    nmax = max(counts)
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} clips, expected {counts[rank]}")
+    padded = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded = torch.cat([local, pad], 0)
+    padded = padded.contiguous()
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.view((world, nmax) + tuple(local.shape[1:])).unbind(0))
+        dist.all_gather(parts, padded, group=group)
+        out = torch.stack(parts, 0).view_as(out)
+    else:
+        dist.all_gather_into_tensor(out, padded, group=group)
+    out = out.view((world, nmax) + tuple(local.shape[1:]))
+    return torch.cat([out[r, :counts[r]] for r in range(world)], 0)
+
+
+def run_sharded(forward_clip, clips: List, n_total: int = None, group=None) -> torch.Tensor:
+    """forward_clip(clip) -> mask tensor [T,Q,h,w]; `clips` is the GLOBAL list (every rank indexes its block)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_total = len(clips) if n_total is None else n_total
+    lo, hi = shard_range(n_total, rank, world)
+    local = torch.stack([forward_clip(clips[i]) for i in range(lo, hi)], 0)
+    return gather_clip_masks(local, n_total, group)

@@ -91,3 +91,24 @@ def test_e2e_swin_t_config2_fullsize_matches_reference():
     """BASELINE config 2 (T=5, 360x640) -- ~15 s of CPU."""
     fx, out = _run_e2e("e2e_swin_t_cfg2.npz", "statedict_swin_t.json", "swin_t_p4w7")
     _check_outputs(fx, out, 5e-3)
+
+
+def test_msda_c_restatement_matches_reference_cases():
+    """oracle/msda_ref.c (scalar C statement of the native kernel's rule) against the reference fixture --
+    including the reference's own D=2 test case (models/ops/test.py:21-26)."""
+    import ctypes
+    from oracle.build_oracle import build
+    lib = ctypes.CDLL(build())
+    fx = load_npz("msda_cases.npz")
+    for i in range(int(fx["n_cases"])):
+        value = np.ascontiguousarray(fx[f"c{i}_value"])
+        loc = np.ascontiguousarray(fx[f"c{i}_loc"])
+        w = np.ascontiguousarray(fx[f"c{i}_w"])
+        shapes = np.ascontiguousarray(fx[f"c{i}_shapes"])
+        lsi = np.concatenate([[0], np.cumsum(shapes[:, 0] * shapes[:, 1])[:-1]]).astype(np.int64)
+        N, S, M, D = value.shape
+        _, Lq, _, L, P, _ = loc.shape
+        out = np.zeros((N, Lq, M * D), dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        lib.msda_ref_forward(p(value), p(shapes), p(lsi), p(loc), p(w), p(out), N, S, M, D, Lq, L, P)
+        assert np.allclose(out, fx[f"c{i}_out"], rtol=1e-4, atol=1e-6), i
