@@ -102,11 +102,14 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
+        graph_mode, model.use_graph = model.use_graph, False  # per-launch events need eager launches
+        step(0)
         ops.GEMM_PROFILE = []
         for i in range(args.steps):
             step(i)
         torch.cuda.synchronize()
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        model.use_graph = graph_mode
         agg = {}
         for tile, conv, flops, e0, e1 in prof:
             a = agg.setdefault((tile, conv), [0.0, 0.0, 0])
@@ -160,6 +163,7 @@ def main():
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans (BASELINE config 2)",
                            "clips_per_step": world, "parallelism": f"clip-sharded x{world}" +
                                                                    (" + RCCL all_gather(pred_masks)" if world > 1 else "")},
+                "launch": "hipGraph replay" if model.use_graph else "eager",
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -52,6 +52,10 @@ typedef struct {
 int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
 /* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
+/* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
+ * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
+int tce_set_gemm_mode(int32_t mode);
+int tce_get_gemm_mode(void);
 
 /* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
  * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */

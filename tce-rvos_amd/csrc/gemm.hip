@@ -200,6 +200,17 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3.hip
+
+static int g_gemm_mode = 1;  // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate)
+
+extern "C" int tce_set_gemm_mode(int32_t mode) {
+  TCE_CHECK_ARG(mode == 0 || mode == 1, "tce_set_gemm_mode: mode must be 0 (f32) or 1 (3xf16 split)");
+  g_gemm_mode = mode;
+  return TCE_OK;
+}
+extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
+
 // tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
 extern "C" int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch) {
@@ -237,6 +248,11 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   const int tile = tce_gemm_select_tile(a.M, a.N, a.batch);
+  if (g_gemm_mode == 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
+    tce_gemm_f16x3_launch(a, tile, s);
+    TCE_CHECK_LAUNCH("tce_gemm_f32(f16x3)");
+    return TCE_OK;
+  }
   if (tile == 128128) launch<128, 128>(a, s);
   else if (tile == 12864) launch<128, 64>(a, s);
   else launch<64, 64>(a, s);

@@ -115,7 +115,11 @@ class ReferFormer(nn.Module):
         self._packed = None
         self._arena = None
         self._shape_cache = {}
+        self._graphs = {}
         self.arena_bytes = None  # override to force an arena size
+        # hipGraph replay of the whole per-clip launch program (one graph per input shape); TCE_GRAPH=0 disables
+        import os
+        self.use_graph = os.environ.get("TCE_GRAPH", "1") != "0"
 
     # ---------------------------------------------------------------- parameter tree
     def _node_for(self, key):
@@ -149,20 +153,22 @@ class ReferFormer(nn.Module):
         rel[:, :, 0] *= 2 * ws - 1
         return rel.sum(-1)
 
-    def _apply(self, fn, *a, **k):
+    def _invalidate(self):
         self._packed = None
         self._shape_cache = {}
+        self._graphs = {}
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        self._packed = None
-        self._shape_cache = {}
+        self._invalidate()
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def repack(self):
-        """Call after mutating parameters in place (the packed kernel operands are derived copies)."""
-        self._packed = None
-        self._shape_cache = {}
+        """Call after mutating parameters in place (packed kernel operands and captured graphs are derived)."""
+        self._invalidate()
 
     # ---------------------------------------------------------------- weight packing
     def _pack(self):
@@ -257,9 +263,13 @@ class ReferFormer(nn.Module):
             self._shape_cache[key] = tp
         return tp
 
-    def _get_arena(self, T, H0, W0, device):
+    def _arena_bytes(self, T, H0, W0):
         tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
-        need = self.arena_bytes or int(tok0 * 4 * (2048 * 2.2 + 256 * 24) + (256 << 20))
+        return self.arena_bytes or int(tok0 * 4 * (2048 * 2.2 + 256 * 24) + (256 << 20))
+
+    def _get_arena(self, T, H0, W0, device):
+        """The eager path's shared arena (captured graphs own a private one each: their addresses are baked in)."""
+        need = self._arena_bytes(T, H0, W0)
         if self._arena is None or self._arena.buf.numel() < need or self._arena.device != torch.device(device):
             self._arena = ops.Arena(device, need)
         return self._arena
@@ -303,8 +313,36 @@ class ReferFormer(nn.Module):
             ids, att = captions, torch.ones_like(captions)
         if bool((att != 1).any()):
             raise NotImplementedError("padded captions (B > 1) are not supported")
-        enc = self.text_encoder(input_ids=ids.to(device), attention_mask=att.to(device))
-        return enc.last_hidden_state.float(), enc.pooler_output.float()
+        ids, att = ids.to(device), att.to(device)
+        if not self.use_graph:
+            enc = self.text_encoder(input_ids=ids, attention_mask=att)
+            return enc.last_hidden_state.float(), enc.pooler_output.float()
+        key = ("text", tuple(ids.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            st_ids, st_att = ids.clone(), att.clone()
+            enc = self.text_encoder(input_ids=st_ids, attention_mask=st_att)  # warm-up (lazy inits inside HF)
+            torch.cuda.synchronize()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    enc = self.text_encoder(input_ids=st_ids, attention_mask=st_att)
+                    outs = (enc.last_hidden_state.float(), enc.pooler_output.float())
+                ent = (graph, st_ids, st_att, outs)
+            except Exception as e:  # the third-party module is not capturable in this version: run it eagerly
+                import warnings
+                warnings.warn(f"text encoder graph capture failed ({type(e).__name__}: {e}); running it eagerly")
+                torch.cuda.synchronize()
+                ent = (None, None, None, None)
+            self._graphs[key] = ent
+        graph, st_ids, st_att, outs = ent
+        if graph is None:
+            enc = self.text_encoder(input_ids=ids, attention_mask=att)
+            return enc.last_hidden_state.float(), enc.pooler_output.float()
+        st_ids.copy_(ids)
+        st_att.copy_(att)
+        graph.replay()
+        return outs[0].clone(), outs[1].clone()
 
     @torch.no_grad()
     def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w):
@@ -312,7 +350,33 @@ class ReferFormer(nn.Module):
         from .pipeline import run_clip
         if self._packed is None:
             self._pack()
-        return run_clip(self, frames, text_hidden.contiguous(), text_pooled.contiguous(), img_h, img_w)
+        text_hidden, text_pooled = text_hidden.contiguous(), text_pooled.contiguous()
+        if not self.use_graph:
+            return run_clip(self, frames, text_hidden, text_pooled, img_h, img_w,
+                            self._get_arena(frames.shape[0], frames.shape[2], frames.shape[3], frames.device))
+        key = (tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training)
+        ent = self._graphs.get(key)
+        if ent is None:
+            T, _, H0, W0 = frames.shape
+            arena = ops.Arena(frames.device, self._arena_bytes(T, H0, W0))
+            st = (torch.empty_like(frames), torch.empty_like(text_hidden), torch.empty_like(text_pooled))
+            for d_, s_ in zip(st, (frames, text_hidden, text_pooled)):
+                d_.copy_(s_)
+            run_clip(self, st[0], st[1], st[2], img_h, img_w, arena)  # eager warm-up: builds the per-shape constants
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run_clip(self, st[0], st[1], st[2], img_h, img_w, arena)
+            ent = (graph, st, out, arena)
+            self._graphs[key] = ent
+        graph, st, out, _ = ent
+        st[0].copy_(frames)
+        st[1].copy_(text_hidden)
+        st[2].copy_(text_pooled)
+        graph.replay()
+        res = {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in a.items()} for a in v])
+               for k, v in out.items()}
+        return res
 
 
 def v_is_conv(t):

@@ -21,11 +21,10 @@ def _lin(A, x, M, K, w, b, N, **kw):
     return out
 
 
-def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w):
+def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
     cfg, w = model.cfg, model._packed
     dev = frames.device
     T, _, H0, W0 = frames.shape
-    ar = model._get_arena(T, H0, W0, dev)
     ar.reset()
     A = ar.alloc
     sc = model._shape_consts(T, H0, W0, dev)
