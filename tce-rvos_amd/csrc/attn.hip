@@ -145,42 +145,61 @@ __global__ void __launch_bounds__(256) window_attn_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Generic multi-head attention, flash-style with KT-key tiles.  Workgroup = NW wavefronts = 64*NW queries of
-// one (batch, head); the K/V tile (KT x 32 floats each) is staged once per workgroup.
+// Generic multi-head attention on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), flash-style.
+//
+// A wavefront owns 32 queries of one (batch, head); a workgroup = NW waves sharing the K/V tiles (32 keys) in LDS.
+// Scores are computed TRANSPOSED, S^T = K Q^T (keys on the MFMA rows, queries on the lanes), so every lane holds
+// 16 of the 32 key scores of ITS query in registers: the row max / sum is 15 in-register ops + one cross-half
+// shuffle, and the probabilities are already the B operand of the second product O^T = V^T P^T (k-step r pairs the
+// keys crow(r,0) / crow(r,1) = the two lane halves of accumulator register r) -- no LDS round trip, no transposes.
+// K rows are padded to 33 floats (the A-operand read walks keys across lanes), V rows are read 32 consecutive
+// floats per half-wave.  Exact fp32 arithmetic (fmaf chains), online softmax with one rescale per 32-key tile.
 // ---------------------------------------------------------------------------------------------------
-template <int KT>
-__global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                  const float* __restrict__ V, float* __restrict__ O, int nheads,
-                                                  int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
-                                                  long long sK, long long sV, long long sO,
-                                                  const uint8_t* __restrict__ kmask, float scale) {
-  __shared__ __attribute__((aligned(16))) float sK_[KT * HD];
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                       const float* __restrict__ V, float* __restrict__ O, int nheads,
+                                                       int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
+                                                       long long sK, long long sV, long long sO,
+                                                       const uint8_t* __restrict__ kmask, float scale) {
+  constexpr int KT = 32, KP = 33;
+  __shared__ float sK_[KT * KP];
   __shared__ __attribute__((aligned(16))) float sV_[KT * HD];
   __shared__ float sM[KT];
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
   const int bh = blockIdx.y;
   const int b = bh / nheads, h = bh - b * nheads;
-  const int qi = blockIdx.x * nthr + tid;
+  const int q0 = (blockIdx.x * (nthr >> 6) + wave) * 32;
+  const int qi = q0 + l31;
   const bool qok = qi < Lq;
   const float* Qb = Q + b * sQ + h * HD;
   const float* Kb = K + b * sK + h * HD;
   const float* Vb = V + b * sV + h * HD;
-  float q[HD], o[HD];
+  // B operand of S^T = K Q^T: lane holds Q[q][d = 2s + lhi] * scale for s = 0..15
+  float qreg[16];
+  {
+    float qrow[HD];
+    if (qok) {
+      const float* p = Qb + (long long)qi * ldq;
 #pragma unroll
-  for (int d = 0; d < HD; ++d) o[d] = 0.f;
-  if (qok) {
-    const float* p = Qb + (long long)qi * ldq;
+      for (int d4 = 0; d4 < 8; ++d4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
 #pragma unroll
-    for (int d4 = 0; d4 < 8; ++d4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
+        for (int j = 0; j < 4; ++j) qrow[d4 * 4 + j] = v[j] * scale;
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[d4 * 4 + j] = v[j] * scale;
+      for (int d = 0; d < HD; ++d) qrow[d] = 0.f;
     }
-  } else {
 #pragma unroll
-    for (int d = 0; d < HD; ++d) q[d] = 0.f;
+    for (int s2 = 0; s2 < 16; ++s2) qreg[s2] = lhi ? qrow[2 * s2 + 1] : qrow[2 * s2];
   }
-  float m = -3.0e38f, l = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -3.0e38f, l = 0.f;  // l is this lane-half's partial sum
   for (int k0 = 0; k0 < Lk; k0 += KT) {
     const int kn = min(KT, Lk - k0);
     __syncthreads();
@@ -191,58 +210,51 @@ __global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ Q, c
         kv = *reinterpret_cast<const f32x4*>(Kb + (long long)(k0 + j) * ldk + d4 * 4);
         vv = *reinterpret_cast<const f32x4*>(Vb + (long long)(k0 + j) * ldv + d4 * 4);
       }
-      *reinterpret_cast<f32x4*>(&sK_[j * HD + d4 * 4]) = kv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sK_[j * KP + d4 * 4 + c] = kv[c];
       *reinterpret_cast<f32x4*>(&sV_[j * HD + d4 * 4]) = vv;
     }
     for (int j = tid; j < KT; j += nthr)
       sM[j] = (j < kn && !(kmask && kmask[(long long)b * Lk + k0 + j])) ? 0.f : -3.0e38f;
     __syncthreads();
-    float s[KT];
+    // S^T[key][q] : A = K[key = l31][d = 2s + lhi], B = qreg[s]
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(sK_[l31 * KP + 2 * s2 + lhi], qreg[s2], st, 0, 0, 0);
     float tmax = -3.0e38f;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      const f32x4* kp = reinterpret_cast<const f32x4*>(&sK_[j * HD]);
-      float a = 0.f;
-#pragma unroll
-      for (int d4 = 0; d4 < 8; ++d4) {
-        const f32x4 kv = kp[d4];
-        a = fmaf(q[d4 * 4 + 0], kv[0], a);
-        a = fmaf(q[d4 * 4 + 1], kv[1], a);
-        a = fmaf(q[d4 * 4 + 2], kv[2], a);
-        a = fmaf(q[d4 * 4 + 3], kv[3], a);
-      }
-      a = fminf(a, 3.0e38f) + sM[j];  // masked / absent keys -> -3e38
-      s[j] = a;
-      tmax = fmaxf(tmax, a);
+    for (int r = 0; r < 16; ++r) {
+      st[r] = fminf(st[r], 3.0e38f) + sM[crow(r, lhi)];
+      tmax = fmaxf(tmax, st[r]);
     }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mnew = fmaxf(m, tmax);
     const float corr = __expf(m - mnew);
     l *= corr;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] *= corr;
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      const float pj = (s[j] > -1.0e38f) ? __expf(s[j] - mnew) : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      o[r] *= corr;
+      const float pj = (st[r] > -1.0e38f) ? __expf(st[r] - mnew) : 0.f;
+      st[r] = pj;
       l += pj;
-      const f32x4* vp = reinterpret_cast<const f32x4*>(&sV_[j * HD]);
-#pragma unroll
-      for (int d4 = 0; d4 < 8; ++d4) {
-        const f32x4 vv = vp[d4];
-        o[d4 * 4 + 0] = fmaf(pj, vv[0], o[d4 * 4 + 0]);
-        o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
-        o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]);
-        o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
-      }
     }
+    // O^T[d][q] += V^T[d][key] P^T[key][q] : k-step r pairs keys crow(r,0), crow(r,1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(sV_[crow(r, lhi) * HD + l31], st[r], o, 0, 0, 0);
     m = mnew;
   }
+  l += __shfl_xor(l, 32, 64);
   if (qok) {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float* po = O + b * sO + (long long)qi * ldo + h * HD;
 #pragma unroll
-    for (int d4 = 0; d4 < 8; ++d4) {
-      f32x4 v = {o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv};
-      *reinterpret_cast<f32x4*>(po + d4 * 4) = v;
+    for (int g4 = 0; g4 < 4; ++g4) {  // registers 4g..4g+3 are 4 consecutive d: d = 8g + 4*lhi + (0..3)
+      f32x4 v = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(po + 8 * g4 + 4 * lhi) = v;
     }
   }
 }
@@ -428,11 +440,11 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
                 "tce_mha_f32: leading dims / strides must be multiples of 4");
   TCE_CHECK_ARG(tce_aligned16(Q) && tce_aligned16(K) && tce_aligned16(V) && tce_aligned16(O),
                 "tce_mha_f32: pointers must be 16-byte aligned");
-  // few queries -> single-wave workgroups for more parallelism
-  const long long blocks256 = (long long)tce_cdiv(Lq, 256) * batch * nheads;
-  const int nthr = (blocks256 >= 512) ? 256 : 64;
-  dim3 grid(tce_cdiv(Lq, nthr), batch * nheads);
-  hipLaunchKernelGGL((mha_kernel<32>), grid, dim3(nthr), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
+  // 32 queries per wavefront; 4 waves share the K/V tiles when there are enough query tiles to fill the chip
+  const long long tiles = (long long)tce_cdiv(Lq, 32) * batch * nheads;
+  const int nw = (tiles >= 4096) ? 4 : 1;
+  dim3 grid(tce_cdiv(Lq, 32 * nw), batch * nheads);
+  hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(64 * nw), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
                      ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
   TCE_CHECK_LAUNCH("tce_mha_f32");
   return TCE_OK;

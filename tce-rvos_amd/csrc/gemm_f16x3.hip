@@ -42,7 +42,7 @@ __device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
 template <int BM, int BN, bool CONV>
-__global__ void __launch_bounds__(256) gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
+__global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NA = BM / 32;  // float4 per thread for the A tile (32 rows per pass)

@@ -62,6 +62,15 @@ def _gemm_launch(g):
     GEMM_PROFILE.append((lib().tce_gemm_select_tile(g.M, g.N, b), bool(g.conv), 2.0 * g.M * g.N * g.K * b, e0, e1))
 
 
+def set_gemm_mode(mode):
+    """'f32' = exact fp32 MFMA; 'f16x3' (default) = fp32 operands split into two fp16 halves, 3 fp16 MFMAs per product."""
+    check(lib().tce_set_gemm_mode({"f32": 0, "f16x3": 1}[mode]), "tce_set_gemm_mode")
+
+
+def get_gemm_mode():
+    return {0: "f32", 1: "f16x3"}[lib().tce_get_gemm_mode()]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

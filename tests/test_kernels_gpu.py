@@ -39,6 +39,28 @@ def test_gemm_plain(ops, M, N, K):
     close(out, F.linear(a, w, b), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 2048), (300, 96, 384)])
+def test_gemm_split_fp16_is_fp32_accurate(ops, M, N, K):
+    """Both GEMM arithmetic modes against an fp64 reference: the 3 x fp16 split must stay within a small factor of
+    the exact-fp32 MFMA kernel's error (and far inside what separates fp16/bf16 GEMMs from fp32)."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)[None, :]   # 4 decades of dynamic range along K
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    ref = (a.double() @ w.double().T)
+    scale = (a.double().abs() @ w.double().abs().T)   # sum |a||b|: the natural error scale
+    errs = {}
+    try:
+        for mode in ("f32", "f16x3"):
+            ops.set_gemm_mode(mode)
+            out = ops.gemm(dev(a), dev(w)).cpu().double()
+            errs[mode] = ((out - ref).abs() / scale).max().item()
+    finally:
+        ops.set_gemm_mode("f16x3")
+    print("relative-to-sum|a||b| errors:", errs)
+    assert errs["f32"] < 2e-6
+    assert errs["f16x3"] < 2e-6 and errs["f16x3"] < 8 * max(errs["f32"], 1e-7)
+
+
 def test_gemm_epilogues_and_prologue(ops):
     g = torch.Generator().manual_seed(3)
     M, N, K = 777, 200, 64
