@@ -54,6 +54,7 @@ int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
 /* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
  * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
+int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 

@@ -16,6 +16,7 @@
 //   * tile ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 // fp32 MFMA issues at the f32 vector rate (157 TFLOP/s peak); it is bit-exact f32 fmaf accumulation in k order.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/tce_rvos.h"
 
 namespace {
@@ -165,26 +166,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, cons
   }
 
   // --- epilogue
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = tn * BN + wn * WN + j * 32 + l31;
-    if (col >= p.N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        if (p.res_mode == 1) v += res[(long long)row * p.ldres + col];
-        else if (p.res_mode == 2) v *= res[(long long)row * p.ldres + col];
-        C[(long long)row * p.ldc + col] = v;
-      }
-    }
+#define EPI_BODY(ACT, RES)                                                                                       \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
+    const int col = tn * BN + wn * WN + j * 32 + l31;                                                            \
+    if (col < p.N) {                                                                                             \
+      const float bv = bias ? bias[col] : 0.f;                                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+          tce_epi_store<ACT, RES>(acc[i][j], bv, res, C, tm * BM + wm * WM + i * 32 + 4 * lhi, col, p.M, p.ldc,  \
+                                  p.ldres);                                                                      \
+    }                                                                                                            \
   }
+  TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
+#undef EPI_BODY
 }
 
 template <int BM, int BN>
@@ -201,6 +194,7 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3.hip
+bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s);        // gemm_f16x3.hip
 
 static int g_gemm_mode = 1;  // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate)
 
@@ -213,7 +207,16 @@ extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
 
 // tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
+static int g_force_tile = 0;
+extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile (tuning aid)
+  TCE_CHECK_ARG(tile == 0 || tile == 1 || tile == 128128 || tile == 12864 || tile == 6464,
+                "tce_gemm_force_tile: bad tile (1 = persistent producer/consumer kernel where applicable)");
+  g_force_tile = tile;
+  return TCE_OK;
+}
+
 extern "C" int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch) {
+  if (g_force_tile) return g_force_tile;
   const long long b = batch > 0 ? batch : 1;
   const long long n128 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 128) * b;
   const long long n12864 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 64) * b;
@@ -249,7 +252,8 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   hipStream_t s = (hipStream_t)stream;
   const int tile = tce_gemm_select_tile(a.M, a.N, a.batch);
   if (g_gemm_mode == 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
-    tce_gemm_f16x3_launch(a, tile, s);
+    // large problems: persistent producer/consumer kernel; small ones: the symmetric tiles
+    if (g_force_tile != 1 || !tce_gemm_f16x3_pc_launch(a, s)) tce_gemm_f16x3_launch(a, tile == 1 ? 12864 : tile, s);
     TCE_CHECK_LAUNCH("tce_gemm_f32(f16x3)");
     return TCE_OK;
   }

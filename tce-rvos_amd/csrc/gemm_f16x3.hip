@@ -18,6 +18,7 @@
 // prefetch of the next K slice during the MFMAs, one barrier per slice.  Per k16 step a wave issues 8
 // ds_read_b128 for 12 MFMAs.  Epilogue identical to the fp32 kernel (bias, ReLU/GELU, residual add/mul).
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/tce_rvos.h"
 
 namespace {
@@ -193,26 +194,21 @@ __global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p,
     __syncthreads();
   }
 
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = tn * BN + wn * WN + j * 32 + l31;
-    if (col >= p.N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row >= p.M) continue;
-        float v = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]) + bv;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        if (p.res_mode == 1) v += res[(long long)row * p.ldres + col];
-        else if (p.res_mode == 2) v *= res[(long long)row * p.ldres + col];
-        C[(long long)row * p.ldc + col] = v;
-      }
-    }
+#define EPI_BODY(ACT, RES)                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+    const int col = tn * BN + wn * WN + j * 32 + l31;                                                       \
+    if (col < p.N) {                                                                                        \
+      const float bv = bias ? bias[col] : 0.f;                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                      \
+        f32x16 x;                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) x[r] = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]);     \
+        tce_epi_store<ACT, RES>(x, bv, res, C, tm * BM + wm * WM + i * 32 + 4 * lhi, col, p.M, p.ldc,       \
+                                p.ldres);                                                                   \
+      }                                                                                                     \
+    }                                                                                                       \
   }
+  TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
+#undef EPI_BODY
 }
 
 template <int BM, int BN>
@@ -233,4 +229,283 @@ int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s) {
   else if (tile == 12864) launch<128, 64>(a, s);
   else launch<64, 64>(a, s);
   return 0;
+}
+
+// =====================================================================================================
+// Producer / consumer persistent variant (the one used for every large problem).
+//
+// The symmetric kernel above is latency-bound: with the MFMAs of a 32-deep slice taking ~0.3 us and one slice
+// of prefetch, every K step waits ~2.5 us for HBM/L2.  Here a 512-thread workgroup (one per CU, persistent over
+// its share of the output tiles) is split by role:
+//   waves 4-7  PRODUCERS: stream fp32 A/W slices from global memory with a DEPTH-slice register ring (their
+//              whole register budget is load buffers), split them into fp16 hi/lo and write the LDS stage;
+//   waves 0-3  CONSUMERS: ds_read_b128 operand fragments + the three MFMAs per product, epilogue.
+// Wave w and w+4 share a SIMD, so the conversion VALU work of a producer co-issues with the MFMAs of its
+// consumer partner.  One workgroup barrier per K slice; two LDS stages; producers keep streaming across tile
+// boundaries, so the next tile's first slices are already in flight while consumers run the epilogue.
+// Tiles are walked in an order that keeps the tiles a given XCD works on adjacent (shared A/W panels in its L2).
+// =====================================================================================================
+namespace {
+
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+struct h4pair {
+  fp16x2_t a, b;
+};
+
+// hi by truncation (v_cvt_pkrtz_f16_f32), lo = the exact remainder, scaled, truncated: |x - hi - lo/2048| <= 2^-20 |x|
+__device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo) {
+  hi.a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+  hi.b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+  const float d0 = (v[0] - (float)hi.a[0]) * LO_SCALE, d1 = (v[1] - (float)hi.a[1]) * LO_SCALE;
+  const float d2 = (v[2] - (float)hi.b[0]) * LO_SCALE, d3 = (v[3] - (float)hi.b[1]) * LO_SCALE;
+  lo.a = __builtin_amdgcn_cvt_pkrtz(d0, d1);
+  lo.b = __builtin_amdgcn_cvt_pkrtz(d2, d3);
+}
+
+constexpr int PC_BM = 128, PC_BN = 128;
+
+template <bool CONV, bool HAS_A2>
+__global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n,
+                                                              const int total_tiles) {
+  constexpr int BM = PC_BM, BN = PC_BN;
+  constexpr int PC_DEPTH = HAS_A2 ? 3 : 4;  // slices in flight per producer thread (register ring)
+  constexpr int PLANE = BM * 64;  // bytes (BM == BN)
+  constexpr int STAGE = 4 * PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int nk = p.K / BK;
+  // persistent tile walk: G workgroups, round j handles tile ids [j*G, (j+1)*G); inside a round the
+  // workgroups of one XCD (b % 8) take a contiguous run of tile ids
+  const int G = gridDim.x;
+  const int per_xcd = G >> 3;  // G is a multiple of 8
+  const int slot_in_round = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int my_tiles = (total_tiles - slot_in_round + G - 1) / G;  // tiles slot, slot+G, ...
+  const long long nsteps = (long long)my_tiles * nk;
+  const int tiles_per_batch = tiles_m * tiles_n;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int ptid = tid - 256;
+    const int kq = ptid & 7, lrow = ptid >> 3;  // 8 threads per 128-byte row segment, 32 rows per pass
+    f32x4 ra[PC_DEPTH][4], rb[PC_DEPTH][4], ra2[HAS_A2 ? PC_DEPTH : 1][4];
+    unsigned okm[PC_DEPTH];  // per ring slot: bit i = A row i valid, bit 4+i = W row i valid (applied at commit)
+    // State of the slice being ISSUED.  Loads are UNCONDITIONAL (rows / pixels outside the problem are clamped to
+    // a valid address and zeroed by a select, steps past the end re-read the last slice) so that the compiler can
+    // keep DEPTH slices in flight behind counted s_waitcnt vmcnt(N) instead of draining at every branch merge.
+    int it_tile = 0, it_k = 0;
+    const float* pa[4];
+    const float* pa2[4];
+    const float* pw[4];
+    bool aok[4], wok[4];
+    int cy[4], cx[4];
+    auto set_tile = [&](int tj) {
+      const int tile = slot_in_round + min(tj, my_tiles - 1) * G;
+      const int bz = tile / tiles_per_batch, r = tile - bz * tiles_per_batch;
+      const int tm = r / tiles_n, tn = r - tm * tiles_n;
+      const float* Ab = p.A + (long long)bz * p.sA;
+      const float* A2b = p.A2 ? p.A2 + (long long)bz * p.sA2 : nullptr;
+      const float* Wb = p.W + (long long)bz * p.sW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm = tm * BM + lrow + 32 * i;
+        aok[i] = gm < p.M;
+        const int gmc = min(gm, p.M - 1);
+        if (CONV) {
+          const int hw = p.Ho * p.Wo;
+          const int t = gmc / hw, rem = gmc - t * hw;
+          cy[i] = (rem / p.Wo) * p.stride - p.pad;
+          cx[i] = (rem % p.Wo) * p.stride - p.pad;
+          pa[i] = Ab + (long long)t * p.H * p.Wd * p.Cin;
+          pa2[i] = nullptr;
+        } else {
+          pa[i] = Ab + (long long)gmc * p.lda;
+          pa2[i] = A2b ? A2b + (long long)gmc * p.lda2 : nullptr;
+          cy[i] = cx[i] = 0;
+        }
+        const int gn = tn * BN + lrow + 32 * i;
+        wok[i] = gn < p.N;
+        pw[i] = Wb + (long long)min(gn, p.N - 1) * p.ldw;
+      }
+    };
+    set_tile(0);
+    auto issue = [&](f32x4 (&xa)[4], f32x4 (&xb)[4], f32x4 (&xa2)[4], unsigned& mask) {
+      unsigned mk = 0;
+      const int k0 = it_k * BK + kq * 4;
+      int tap = 0, ky = 0, kx = 0, c0 = k0;
+      if (CONV) {
+        tap = (it_k * BK) / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v;
+        bool ok = aok[i];
+        if (CONV) {
+          const int yi = cy[i] + ky, xi = cx[i] + kx;
+          ok = ok && yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd;
+          const int yc = min(max(yi, 0), p.H - 1), xc = min(max(xi, 0), p.Wd - 1);
+          v = *reinterpret_cast<const f32x4*>(pa[i] + ((long long)yc * p.Wd + xc) * p.Cin + c0);
+        } else {
+          v = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+          if (HAS_A2) xa2[i] = *reinterpret_cast<const f32x4*>(pa2[i] + k0);  // added at commit time (no wait here)
+        }
+        xa[i] = v;
+        xb[i] = *reinterpret_cast<const f32x4*>(pw[i] + k0);
+        mk |= (ok ? 1u : 0u) << i;
+        mk |= (wok[i] ? 1u : 0u) << (4 + i);
+      }
+      mask = mk;
+      if (++it_k == nk) {
+        it_k = 0;
+        ++it_tile;
+        set_tile(it_tile);
+      }
+    };
+    auto commit = [&](const f32x4 (&xa)[4], const f32x4 (&xb)[4], const f32x4 (&xa2)[4], unsigned mask, int buf) {
+      unsigned char* st = smem + buf * STAGE;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = lrow + 32 * i;
+        const int off = swz(row, kq >> 1) + ((kq & 1) << 3);
+        h4pair hi, lo;
+        f32x4 av = xa[i];
+        if (HAS_A2) av += xa2[i];
+        split4_rtz(((mask >> i) & 1u) ? av : zero, hi, lo);
+        *reinterpret_cast<h4pair*>(st + off) = hi;
+        *reinterpret_cast<h4pair*>(st + PLANE + off) = lo;
+        split4_rtz(((mask >> (4 + i)) & 1u) ? xb[i] : zero, hi, lo);
+        *reinterpret_cast<h4pair*>(st + 2 * PLANE + off) = hi;
+        *reinterpret_cast<h4pair*>(st + 3 * PLANE + off) = lo;
+      }
+    };
+    // prologue: slices 0..DEPTH-1 in flight, slice 0 committed to stage 0
+#pragma unroll
+    for (int d = 0; d < PC_DEPTH; ++d) issue(ra[d], rb[d], ra2[HAS_A2 ? d : 0], okm[d]);
+    commit(ra[0], rb[0], ra2[0], okm[0], 0);
+    issue(ra[0], rb[0], ra2[0], okm[0]);  // slice DEPTH
+    __syncthreads();
+    // step s: consumers multiply stage s&1; producers commit slice s+1 into stage (s+1)&1 and refill its ring slot.
+    // The steady-state loop is branch-free (committing / issuing past the end is harmless: loads are clamped and
+    // the stage written is never read) so that the compiler keeps exact vmcnt counts across the ring.
+    long long s0 = 0;
+    for (; s0 + PC_DEPTH <= nsteps; s0 += PC_DEPTH) {
+#pragma unroll
+      for (int d = 0; d < PC_DEPTH; ++d) {
+        const int r = (d + 1) % PC_DEPTH;  // ring slot holding slice s+1
+        commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (int)((s0 + d + 1) & 1));
+        issue(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r]);  // slice s+1+DEPTH
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < PC_DEPTH; ++d) {
+      if (s0 + d < nsteps) {
+        const int r = (d + 1) % PC_DEPTH;
+        commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (int)((s0 + d + 1) & 1));
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        acx[i][j][r] = 0.f;
+      }
+  __syncthreads();  // pairs with the producers' prologue barrier
+  int tj = 0, kt = 0;
+  for (long long s = 0; s < nsteps; ++s) {
+    const unsigned char* st = smem + (int)(s & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 2 + lhi;
+      h16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = swz(wm * 64 + i * 32 + l31, c);
+        ah[i] = *reinterpret_cast<const h16x8*>(st + off);
+        al[i] = *reinterpret_cast<const h16x8*>(st + PLANE + off);
+        const int offb = swz(wn * 64 + i * 32 + l31, c);
+        bh[i] = *reinterpret_cast<const h16x8*>(st + 2 * PLANE + offb);
+        bl[i] = *reinterpret_cast<const h16x8*>(st + 3 * PLANE + offb);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+        }
+    }
+    if (++kt == nk) {
+      // epilogue of tile tj (the producers are already streaming the next tile)
+      const int tile = slot_in_round + tj * G;
+      const int bz = tile / tiles_per_batch, rr = tile - bz * tiles_per_batch;
+      const int tm = rr / tiles_n, tn = rr - tm * tiles_n;
+      const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
+      const float* __restrict__ res = p.res ? p.res + (long long)bz * p.sRes : nullptr;
+      float* __restrict__ C = p.C + (long long)bz * p.sC;
+#define EPI_BODY(ACT, RES)                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
+    const int col = tn * BN + wn * 64 + j * 32 + l31;                                                       \
+    const bool cok = col < p.N;                                                                             \
+    const float bv = (bias && cok) ? bias[col] : 0.f;                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
+      f32x16 x;                                                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
+        x[r] = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]);                                                    \
+        acc[i][j][r] = 0.f;                                                                                 \
+        acx[i][j][r] = 0.f;                                                                                 \
+      }                                                                                                     \
+      if (cok) tce_epi_store<ACT, RES>(x, bv, res, C, tm * BM + wm * 64 + i * 32 + 4 * lhi, col, p.M, p.ldc, \
+                                       p.ldres);                                                            \
+    }                                                                                                       \
+  }
+      TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
+#undef EPI_BODY
+      kt = 0;
+      ++tj;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// persistent producer/consumer launch; returns false if the problem is too small to fill the chip this way
+bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s) {
+  const int tiles_m = tce_cdiv(a.M, PC_BM), tiles_n = tce_cdiv(a.N, PC_BN);
+  const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
+  if (total < 192 || total > 0x7fffffff) return false;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    n_cu &= ~7;
+  }
+  const int G = (int)((total < n_cu) ? ((total + 7) & ~7LL) : n_cu);
+  if (a.conv)
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<true, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+  else if (a.A2)
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, true>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+  else
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+  return true;
 }

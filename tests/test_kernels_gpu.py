@@ -31,7 +31,8 @@ def close(a, b, rtol=1e-4, atol=1e-4):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 16), (25, 256, 256), (130, 70, 48 * 2), (300, 384, 96), (1200, 2048, 256),
-                                   (4097, 96, 384), (513, 2153, 256)])
+                                   (4097, 96, 384), (513, 2153, 256), (3333, 1000, 160), (24100, 256, 64),
+                                   (2049, 1500, 32)])
 def test_gemm_plain(ops, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
@@ -81,9 +82,25 @@ def test_gemm_epilogues_and_prologue(ops):
     assert outw[:, :N].abs().sum().item() == 0
 
 
-def test_gemm_batched(ops):
+def test_gemm_large_epilogues_shared_addend(ops):
+    """Large problem (persistent producer/consumer kernel): frame-batched launch with a stride-0 shared addend,
+    bias + ReLU + residual, output written into a level slice of a wider [T, S, C] buffer."""
+    g = torch.Generator().manual_seed(8)
+    T, hw, S, K, N = 5, 3600, 4820, 256, 256
+    a, pos = torch.randn(T, hw, K, generator=g), torch.randn(hw, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / 16, torch.randn(N, generator=g)
+    r = torch.randn(T, hw, N, generator=g)
+    out = torch.zeros(T, S, N, device="cuda")
+    ops.gemm_ex(dev(a), dev(w), out[:, 100:], hw, N, K, K, K, N, bias=dev(b), a2=dev(pos), lda2=K, act=ops.ACT_RELU,
+                res=dev(r), ldres=N, res_mode=ops.RES_MUL, batch=T, sA=hw * K, sA2=0, sC=S * N, sRes=hw * N)
+    ref = torch.relu(F.linear(a + pos[None], w, b)) * r
+    close(out[:, 100:100 + hw], ref, 1e-4, 1e-4)
+    assert out[:, :100].abs().sum().item() == 0 and out[:, 100 + hw:].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("B,M,N,K", [(3, 333, 160, 256), (5, 4820, 384, 256)])
+def test_gemm_batched(ops, B, M, N, K):
     g = torch.Generator().manual_seed(4)
-    B, M, N, K = 3, 333, 160, 256
     a, w = torch.randn(B, M, K, generator=g), torch.randn(B, N, K, generator=g) / 16
     out = torch.empty(B, M, N, device="cuda")
     ops.gemm_batched(dev(a), dev(w), out)
@@ -91,7 +108,8 @@ def test_gemm_batched(ops):
 
 
 @pytest.mark.parametrize("T,H,W,Cin,N,k,s,p", [(2, 9, 13, 32, 48, 3, 1, 1), (3, 12, 20, 64, 256, 3, 2, 1),
-                                                (1, 23, 40, 256, 256, 3, 1, 1), (2, 7, 5, 16, 33, 1, 1, 0)])
+                                                (1, 23, 40, 256, 256, 3, 1, 1), (2, 7, 5, 16, 33, 1, 1, 0),
+                                                (4, 45, 81, 64, 250, 3, 1, 1), (3, 90, 61, 32, 256, 3, 2, 1)])
 def test_conv_implicit_gemm(ops, T, H, W, Cin, N, k, s, p):
     g = torch.Generator().manual_seed(T + H + N)
     x = torch.randn(T, Cin, H, W, generator=g)
