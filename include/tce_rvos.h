@@ -52,6 +52,7 @@ typedef struct {
 int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
 /* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
+int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t conv);
 /* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
  * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
 int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */

@@ -209,20 +209,34 @@ extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
 static int g_force_tile = 0;
 extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile (tuning aid)
-  TCE_CHECK_ARG(tile == 0 || tile == 1 || tile == 128128 || tile == 12864 || tile == 6464,
+  TCE_CHECK_ARG(tile == 0 || tile == 1 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465 || tile == 256129 || tile == 256130 || tile == 12865,
                 "tce_gemm_force_tile: bad tile (1 = persistent producer/consumer kernel where applicable)");
   g_force_tile = tile;
   return TCE_OK;
 }
 
-extern "C" int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch) {
+static int select_tile_ex(int M, int N, int K, int batch, int conv) {
   if (g_force_tile) return g_force_tile;
   const long long b = batch > 0 ? batch : 1;
+  const long long n256 = (long long)tce_cdiv(M, 256) * tce_cdiv(N, 128) * b;
   const long long n128 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 128) * b;
   const long long n12864 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 64) * b;
+  if (g_gemm_mode == 1) {
+    // measured on MI355X (tools/gemm_bench.py): the 8-wave 256x128 tile wins once it fills the chip 1.5x and the
+    // problem is wide or deep; 128x128 for the big implicit-GEMM convolutions; the small tiles elsewhere
+    if (n256 >= 384 && (N >= 512 || K >= 1024) && !conv) return 256128;
+    if (conv && n128 >= 256) return 128128;
+    if (n12864 >= 384 && M > 64) return 12864;
+    return 6464;
+  }
   if (n128 >= 512 && N > 64) return 128128;
   if (n12864 >= 384 && M > 64) return 12864;
   return 6464;
+}
+
+extern "C" int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch) { return select_tile_ex(M, N, 0, batch, 0); }
+extern "C" int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t conv) {
+  return select_tile_ex(M, N, K, batch, conv);
 }
 
 extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
@@ -250,14 +264,15 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
     TCE_CHECK_ARG(!a.A2 || (a.lda2 % 4 == 0 && a.lda2 >= a.K), "tce_gemm_f32: lda2 invalid");
   }
   hipStream_t s = (hipStream_t)stream;
-  const int tile = tce_gemm_select_tile(a.M, a.N, a.batch);
+  const int tile = select_tile_ex(a.M, a.N, a.K, a.batch, a.conv);
   if (g_gemm_mode == 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
     // large problems: persistent producer/consumer kernel; small ones: the symmetric tiles
     if (g_force_tile != 1 || !tce_gemm_f16x3_pc_launch(a, s)) tce_gemm_f16x3_launch(a, tile == 1 ? 12864 : tile, s);
     TCE_CHECK_LAUNCH("tce_gemm_f32(f16x3)");
     return TCE_OK;
   }
-  if (tile == 128128) launch<128, 128>(a, s);
+  if (tile == 128128 || tile == 256128) launch<128, 128>(a, s);
+  else if (tile == 6465) launch<64, 64>(a, s);
   else if (tile == 12864) launch<128, 64>(a, s);
   else launch<64, 64>(a, s);
   TCE_CHECK_LAUNCH("tce_gemm_f32");

@@ -42,13 +42,35 @@ __device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
 // byte offset of (row, 16-byte chunk c) inside a plane with 64-byte rows
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-template <int BM, int BN, bool CONV>
-__global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
-  constexpr int WM = BM / 2, WN = BN / 2;
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+struct h4pair {
+  fp16x2_t a, b;
+};
+
+// hi by truncation (v_cvt_pkrtz_f16_f32), lo = the exact remainder, scaled, truncated: |x - hi - lo/2048| <= 2^-20 |x|
+__device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo) {
+  hi.a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+  hi.b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+  const float d0 = (v[0] - (float)hi.a[0]) * LO_SCALE, d1 = (v[1] - (float)hi.a[1]) * LO_SCALE;
+  const float d2 = (v[2] - (float)hi.b[0]) * LO_SCALE, d3 = (v[3] - (float)hi.b[1]) * LO_SCALE;
+  lo.a = __builtin_amdgcn_cvt_pkrtz(d0, d1);
+  lo.b = __builtin_amdgcn_cvt_pkrtz(d2, d3);
+}
+
+// Symmetric kernel: every wave loads, converts and multiplies.  DEPTH K-slices are kept in flight per thread in a
+// register ring (loads are unconditional -- clamped addresses, validity applied at commit -- and the steady-state
+// loop is branch-free, so the compiler emits exact counted vmcnt waits): a K step no longer pays a full memory
+// round trip, which is what bounds the small / short-K problems of this path.
+template <int BM, int BN, int WAVES_M, bool CONV, bool HAS_A2, int DEPTH>
+__global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
+    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
+  constexpr int NT = 128 * WAVES_M;                   // threads: WAVES_M x 2 waves
+  constexpr int RP = NT / 8;                          // tile rows covered by one loader pass
+  constexpr int WM = BM / WAVES_M, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int NA = BM / 32;  // float4 per thread for the A tile (32 rows per pass)
-  constexpr int NB = BN / 32;
-  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;       // bytes
+  constexpr int NA = BM / RP;  // float4 per thread for the A tile
+  constexpr int NB = BN / RP;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;  // bytes
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
@@ -61,87 +83,96 @@ __global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p,
   const int bz = blockIdx.z;
 
   const float* __restrict__ A = p.A + (long long)bz * p.sA;
-  const float* __restrict__ A2 = p.A2 ? p.A2 + (long long)bz * p.sA2 : nullptr;
+  const float* __restrict__ A2 = HAS_A2 ? p.A2 + (long long)bz * p.sA2 : nullptr;
   const float* __restrict__ W = p.W + (long long)bz * p.sW;
   const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
   const float* __restrict__ res = p.res ? p.res + (long long)bz * p.sRes : nullptr;
   float* __restrict__ C = p.C + (long long)bz * p.sC;
 
   const int kq = tid & 7;     // which float4 of the 32-wide K slice
-  const int lrow = tid >> 3;  // 0..31
-  long long a_off[NA];
-  bool a_ok[NA];
-  int c_t[NA], c_y[NA], c_x[NA];
+  const int lrow = tid >> 3;  // 0..RP-1
+  const float* pa[NA];
+  const float* pa2[NA];
+  unsigned rowmask = 0;  // bit i: A row i inside M; bit 8+i: W row i inside N
+  int c_y[NA], c_x[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int gm = tm * BM + lrow + 32 * i;
-    a_ok[i] = gm < p.M;
+    const int gm = tm * BM + lrow + RP * i;
+    if (gm < p.M) rowmask |= 1u << i;
+    const int gmc = min(gm, p.M - 1);
     if (CONV) {
       const int hw = p.Ho * p.Wo;
-      const int t = gm / hw, rem = gm - t * hw;
-      c_t[i] = t;
+      const int t = gmc / hw, rem = gmc - t * hw;
       c_y[i] = (rem / p.Wo) * p.stride - p.pad;
       c_x[i] = (rem % p.Wo) * p.stride - p.pad;
-      a_off[i] = 0;
+      pa[i] = A + (long long)t * p.H * p.Wd * p.Cin;
+      pa2[i] = nullptr;
     } else {
-      a_off[i] = (long long)gm * p.lda;
-      c_t[i] = c_y[i] = c_x[i] = 0;
+      pa[i] = A + (long long)gmc * p.lda;
+      pa2[i] = HAS_A2 ? A2 + (long long)gmc * p.lda2 : nullptr;
+      c_y[i] = c_x[i] = 0;
     }
   }
-  long long w_off[NB];
-  bool w_ok[NB];
+  const float* pw[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int gn = tn * BN + lrow + 32 * i;
-    w_ok[i] = gn < p.N;
-    w_off[i] = (long long)gn * p.ldw;
+    const int gn = tn * BN + lrow + RP * i;
+    if (gn < p.N) rowmask |= 1u << (8 + i);
+    pw[i] = W + (long long)min(gn, p.N - 1) * p.ldw;
   }
+  const int nk = p.K / BK;
 
-  f32x4 ra[NA], rb[NB];
-  auto load_tiles = [&](int kt) {
+  f32x4 ra[DEPTH][NA], rb[DEPTH][NB], ra2[HAS_A2 ? DEPTH : 1][NA];
+  unsigned okm[DEPTH];
+  auto issue = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], f32x4 (&xa2)[NA], unsigned& mask, int kt) {
+    kt = min(kt, nk - 1);  // past the end: re-read the last slice (never committed)
     const int k0 = kt * BK + kq * 4;
+    unsigned mk = rowmask;
+    int ky = 0, kx = 0, c0 = k0;
+    if (CONV) {
+      const int tap = (kt * BK) / p.Cin;
+      c0 = k0 - tap * p.Cin;
+      ky = tap / p.kw;
+      kx = tap - ky * p.kw;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (CONV) {
-        const int tap = (kt * BK) / p.Cin;
-        const int c0 = k0 - tap * p.Cin;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
         const int yi = c_y[i] + ky, xi = c_x[i] + kx;
-        if (a_ok[i] && yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd)
-          v = *reinterpret_cast<const f32x4*>(A + (((long long)c_t[i] * p.H + yi) * p.Wd + xi) * p.Cin + c0);
-      } else if (a_ok[i]) {
-        v = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
-        if (A2) v += *reinterpret_cast<const f32x4*>(A2 + (long long)(tm * BM + lrow + 32 * i) * p.lda2 + k0);
+        if (!(yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd)) mk &= ~(1u << i);
+        const int yc = min(max(yi, 0), p.H - 1), xc = min(max(xi, 0), p.Wd - 1);
+        xa[i] = *reinterpret_cast<const f32x4*>(pa[i] + ((long long)yc * p.Wd + xc) * p.Cin + c0);
+      } else {
+        xa[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+        if (HAS_A2) xa2[i] = *reinterpret_cast<const f32x4*>(pa2[i] + k0);
       }
-      ra[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (w_ok[i]) v = *reinterpret_cast<const f32x4*>(W + w_off[i] + k0);
-      rb[i] = v;
-    }
+    for (int i = 0; i < NB; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pw[i] + k0);
+    mask = mk;
   };
-  auto store_tiles = [&](int buf) {
+  auto commit = [&](const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], const f32x4 (&xa2)[NA], unsigned mask, int buf) {
     unsigned char* st = smem + buf * STAGE;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row = lrow + 32 * i;
+      const int row = lrow + RP * i;
       const int off = swz(row, kq >> 1) + ((kq & 1) << 3);
-      h16x4 hi, lo;
-      split4(ra[i], hi, lo);
-      *reinterpret_cast<h16x4*>(st + off) = hi;
-      *reinterpret_cast<h16x4*>(st + PLANE_A + off) = lo;
+      f32x4 av = xa[i];
+      if (HAS_A2) av += xa2[i];
+      h4pair hi, lo;
+      split4_rtz(((mask >> i) & 1u) ? av : zero, hi, lo);
+      *reinterpret_cast<h4pair*>(st + off) = hi;
+      *reinterpret_cast<h4pair*>(st + PLANE_A + off) = lo;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int row = lrow + 32 * i;
+      const int row = lrow + RP * i;
       const int off = swz(row, kq >> 1) + ((kq & 1) << 3);
-      h16x4 hi, lo;
-      split4(rb[i], hi, lo);
-      *reinterpret_cast<h16x4*>(st + 2 * PLANE_A + off) = hi;
-      *reinterpret_cast<h16x4*>(st + 2 * PLANE_A + PLANE_B + off) = lo;
+      h4pair hi, lo;
+      split4_rtz(((mask >> (8 + i)) & 1u) ? xb[i] : zero, hi, lo);
+      *reinterpret_cast<h4pair*>(st + 2 * PLANE_A + off) = hi;
+      *reinterpret_cast<h4pair*>(st + 2 * PLANE_A + PLANE_B + off) = lo;
     }
   };
 
@@ -155,15 +186,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p,
         acc[i][j][r] = 0.f;
         acx[i][j][r] = 0.f;
       }
-
-  const int nk = p.K / BK;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  auto compute = [&](int buf) {
     const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -190,8 +214,35 @@ __global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p,
           acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    __syncthreads();
+  };
+
+  // prologue: slices 0..DEPTH-1 in flight; slice 0 committed; slice DEPTH issued into the freed slot
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(ra[d], rb[d], ra2[HAS_A2 ? d : 0], okm[d], d);
+  commit(ra[0], rb[0], ra2[0], okm[0], 0);
+  issue(ra[0], rb[0], ra2[0], okm[0], DEPTH);
+  __syncthreads();
+  int kt0 = 0;
+  for (; kt0 + DEPTH <= nk; kt0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int kt = kt0 + d;
+      const int r = (d + 1) % DEPTH;  // ring slot holding slice kt+1
+      compute(kt & 1);
+      commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (kt + 1) & 1);
+      issue(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], kt + 1 + DEPTH);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int kt = kt0 + d;
+    if (kt < nk) {
+      const int r = (d + 1) % DEPTH;
+      compute(kt & 1);
+      commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (kt + 1) & 1);
+      __syncthreads();
+    }
   }
 
 #define EPI_BODY(ACT, RES)                                                                                  \
@@ -211,23 +262,34 @@ __global__ void __launch_bounds__(256, 2) gemm_f16x3_kernel(const tceGemmArgs p,
 #undef EPI_BODY
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M, int DEPTH>
 void launch(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
-  dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1);
+  dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1), block(128 * WAVES_M);
   if (a.conv)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, true>), grid, dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
+  else if (a.A2)
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, false>), grid, dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
 }
 
 }  // namespace
 
 // called by tce_gemm_f32 (gemm.hip) after argument validation when the split mode is selected and K % 32 == 0
 int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s) {
-  if (tile == 128128) launch<128, 128>(a, s);
-  else if (tile == 12864) launch<128, 64>(a, s);
-  else launch<64, 64>(a, s);
+  if (tile == 256128) launch<256, 128, 4, 1>(a, s);   // 512 threads, 8 waves of 64x64
+  else if (tile == 256129) launch<256, 128, 4, 2>(a, s);
+  else if (tile == 256130) launch<256, 128, 4, 3>(a, s);
+  else if (tile == 128128) launch<128, 128, 2, 1>(a, s);
+  else if (tile == 12864) launch<128, 64, 2, 1>(a, s);
+  else if (tile == 12865) launch<128, 64, 2, 2>(a, s);
+  else {
+    // few workgroups = nothing else on the CU to hide a K step's memory round trip: keep 4 slices in flight
+    const long long blocks = (long long)tce_cdiv(a.M, 64) * tce_cdiv(a.N, 64) * (a.batch > 0 ? a.batch : 1);
+    if (blocks < 512 || tile == 6465) launch<64, 64, 2, 4>(a, s);
+    else launch<64, 64, 2, 1>(a, s);
+  }
   return 0;
 }
 
@@ -246,22 +308,6 @@ int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s) {
 // Tiles are walked in an order that keeps the tiles a given XCD works on adjacent (shared A/W panels in its L2).
 // =====================================================================================================
 namespace {
-
-typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-
-struct h4pair {
-  fp16x2_t a, b;
-};
-
-// hi by truncation (v_cvt_pkrtz_f16_f32), lo = the exact remainder, scaled, truncated: |x - hi - lo/2048| <= 2^-20 |x|
-__device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo) {
-  hi.a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-  hi.b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-  const float d0 = (v[0] - (float)hi.a[0]) * LO_SCALE, d1 = (v[1] - (float)hi.a[1]) * LO_SCALE;
-  const float d2 = (v[2] - (float)hi.b[0]) * LO_SCALE, d3 = (v[3] - (float)hi.b[1]) * LO_SCALE;
-  lo.a = __builtin_amdgcn_cvt_pkrtz(d0, d1);
-  lo.b = __builtin_amdgcn_cvt_pkrtz(d2, d3);
-}
 
 constexpr int PC_BM = 128, PC_BN = 128;
 

@@ -275,12 +275,18 @@ class ReferFormer(nn.Module):
         return self._arena
 
     # ---------------------------------------------------------------- the boundary
+    @torch.no_grad()
     def forward(self, samples, captions, targets):
         """models/tce_rvos.py:194.  samples: NestedTensor([B,T,3,H,W],[B,T,H,W]) or list of [T,3,H,W];
         captions: list[str] (or a LongTensor [B,L] of token ids); targets: list[dict] with 'size'."""
         if not isinstance(samples, NestedTensor) and not (hasattr(samples, "tensors") and hasattr(samples, "mask")):
-            samples = nested_tensor_from_videos_list(samples)
-        vids, mask = samples.tensors, samples.mask
+            if len(samples) == 1:  # a single clip is never padded: no copy, no mask, no host sync
+                vids, mask = samples[0][None], None
+            else:
+                samples = nested_tensor_from_videos_list(samples)
+                vids, mask = samples.tensors, samples.mask
+        else:
+            vids, mask = samples.tensors, samples.mask
         if isinstance(captions, (list, tuple)):
             if not isinstance(captions[0], str):
                 raise ValueError("Please mask sure the caption is a list of string")
@@ -299,84 +305,103 @@ class ReferFormer(nn.Module):
         if mask is not None and bool(mask.any()):
             raise NotImplementedError("padded clips are not supported (a single clip is never padded)")
         frames = vids[0].to(torch.float32).contiguous()
-        hid, pooled = self.forward_text_encoder(captions, frames.device)
         size = targets[0]["size"]
         img_h, img_w = float(size[0]), float(size[1])
-        return self.forward_features(frames, hid[0], pooled[0], img_h, img_w)
+        ids, att = self._tokenise(captions, frames.device)
+        if self._packed is None:
+            self._pack()
+        if not self.use_graph:
+            hid, pooled = self._text_eager(ids, att)
+            return self._run(frames, (hid[0].contiguous(), pooled[0].contiguous()), img_h, img_w, None)
+        # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder beside
+        # the pixel decoder
+        key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training)
+        ent = self._graphs.get(key)
+        if ent is None:
+            st = (frames.clone(), ids.clone(), att.clone())
 
-    @torch.no_grad()
-    def forward_text_encoder(self, captions, device):
-        """tce_rvos.py:406-424 up to the RoBERTa outputs (third-party arithmetic, runs on PyTorch-ROCm)."""
+            def text_fn():
+                hid, pooled = self._text_eager(st[1], st[2])
+                return hid[0].contiguous(), pooled[0].contiguous()
+
+            ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames)
+        return self._replay(ent, (frames, ids, att))
+
+    def _tokenise(self, captions, device):
         if isinstance(captions, (list, tuple)):
             ids, att = self.tokenizer(list(captions))
         else:
             ids, att = captions, torch.ones_like(captions)
         if bool((att != 1).any()):
             raise NotImplementedError("padded captions (B > 1) are not supported")
-        ids, att = ids.to(device), att.to(device)
-        if not self.use_graph:
-            enc = self.text_encoder(input_ids=ids, attention_mask=att)
-            return enc.last_hidden_state.float(), enc.pooler_output.float()
-        key = ("text", tuple(ids.shape))
-        ent = self._graphs.get(key)
-        if ent is None:
-            st_ids, st_att = ids.clone(), att.clone()
-            enc = self.text_encoder(input_ids=st_ids, attention_mask=st_att)  # warm-up (lazy inits inside HF)
-            torch.cuda.synchronize()
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    enc = self.text_encoder(input_ids=st_ids, attention_mask=st_att)
-                    outs = (enc.last_hidden_state.float(), enc.pooler_output.float())
-                ent = (graph, st_ids, st_att, outs)
-            except Exception as e:  # the third-party module is not capturable in this version: run it eagerly
-                import warnings
-                warnings.warn(f"text encoder graph capture failed ({type(e).__name__}: {e}); running it eagerly")
-                torch.cuda.synchronize()
-                ent = (None, None, None, None)
-            self._graphs[key] = ent
-        graph, st_ids, st_att, outs = ent
-        if graph is None:
-            enc = self.text_encoder(input_ids=ids, attention_mask=att)
-            return enc.last_hidden_state.float(), enc.pooler_output.float()
-        st_ids.copy_(ids)
-        st_att.copy_(att)
+        return ids.to(device), att.to(device)
+
+    def _text_eager(self, ids, att):
+        enc = self.text_encoder(input_ids=ids, attention_mask=att)
+        return enc.last_hidden_state.float(), enc.pooler_output.float()
+
+    def _run(self, frames, text, img_h, img_w, res):
+        from .pipeline import run_clip
+        T, _, H0, W0 = frames.shape
+        if res is None:  # eager: shared arena, single stream
+            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device))
+        arena, side_arena, side_stream = res
+        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream)
+
+    def _capture(self, key, statics, fn, like):
+        """Captures fn((arena, side_arena, side_stream)) into a graph; the arenas belong to the graph (their
+        addresses are baked into it)."""
+        T, _, H0, W0 = like.shape
+        res = (ops.Arena(like.device, self._arena_bytes(T, H0, W0)),
+               ops.Arena(like.device, T * self._tokens_per_frame(H0, W0) * 256 * 4 * 4 + (32 << 20)),
+               torch.cuda.Stream(device=like.device))
+        fn(None if False else res)  # eager warm-up on the same resources: builds per-shape constants, lazy inits
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn(res)
+        ent = (graph, statics, out, res)
+        self._graphs[key] = ent
+        return ent
+
+    @staticmethod
+    def _tokens_per_frame(H0, W0):
+        h, w = (H0 + 3) // 4, (W0 + 3) // 4
+        n = 0
+        for _ in range(3):
+            h, w = (h + 1) // 2, (w + 1) // 2
+            n += h * w
+        return n + ((h + 1) // 2) * ((w + 1) // 2)
+
+    @staticmethod
+    def _replay(ent, inputs):
+        graph, statics, out, _ = ent
+        for d_, s_ in zip(statics, inputs):
+            d_.copy_(s_)
         graph.replay()
-        return outs[0].clone(), outs[1].clone()
+        return {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in a.items()} for a in v])
+                for k, v in out.items()}
+
+    @torch.no_grad()
+    def forward_text_encoder(self, captions, device):
+        """tce_rvos.py:406-424 up to the RoBERTa outputs (third-party arithmetic, runs on PyTorch-ROCm)."""
+        ids, att = self._tokenise(captions, device)
+        return self._text_eager(ids, att)
 
     @torch.no_grad()
     def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w):
         """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768]."""
-        from .pipeline import run_clip
         if self._packed is None:
             self._pack()
         text_hidden, text_pooled = text_hidden.contiguous(), text_pooled.contiguous()
         if not self.use_graph:
-            return run_clip(self, frames, text_hidden, text_pooled, img_h, img_w,
-                            self._get_arena(frames.shape[0], frames.shape[2], frames.shape[3], frames.device))
-        key = (tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training)
+            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None)
+        key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training)
         ent = self._graphs.get(key)
         if ent is None:
-            T, _, H0, W0 = frames.shape
-            arena = ops.Arena(frames.device, self._arena_bytes(T, H0, W0))
-            st = (torch.empty_like(frames), torch.empty_like(text_hidden), torch.empty_like(text_pooled))
-            for d_, s_ in zip(st, (frames, text_hidden, text_pooled)):
-                d_.copy_(s_)
-            run_clip(self, st[0], st[1], st[2], img_h, img_w, arena)  # eager warm-up: builds the per-shape constants
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = run_clip(self, st[0], st[1], st[2], img_h, img_w, arena)
-            ent = (graph, st, out, arena)
-            self._graphs[key] = ent
-        graph, st, out, _ = ent
-        st[0].copy_(frames)
-        st[1].copy_(text_hidden)
-        st[2].copy_(text_pooled)
-        graph.replay()
-        res = {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in a.items()} for a in v])
-               for k, v in out.items()}
-        return res
+            st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
+            ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res), frames)
+        return self._replay(ent, (frames, text_hidden, text_pooled))
 
 
 def v_is_conv(t):

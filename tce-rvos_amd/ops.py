@@ -59,7 +59,7 @@ def _gemm_launch(g):
     check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
     e1.record()
     b = max(1, g.batch)
-    GEMM_PROFILE.append((lib().tce_gemm_select_tile(g.M, g.N, b), bool(g.conv), 2.0 * g.M * g.N * g.K * b, e0, e1))
+    GEMM_PROFILE.append((lib().tce_gemm_select_tile_ex(g.M, g.N, g.K, b, g.conv), bool(g.conv), 2.0 * g.M * g.N * g.K * b, e0, e1))
 
 
 def set_gemm_mode(mode):

@@ -21,11 +21,49 @@ def _lin(A, x, M, K, w, b, N, **kw):
     return out
 
 
-def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
+class _Fork:
+    """Runs a block of launches on a side stream (inside hipGraph capture this becomes a parallel graph branch);
+    without a side stream it degenerates to in-order execution on the current stream."""
+
+    def __init__(self, side_stream):
+        self.side = side_stream
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None):
+    """text: (last_hidden_state [L,768], pooler_output [768]) or a callable returning them (the RoBERTa forward,
+    run as a parallel branch beside the backbone when a side stream is given).
+    side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
+    beside the pixel decoder's large kernels; it needs its own arena because both branches allocate."""
     cfg, w = model.cfg, model._packed
     dev = frames.device
     T, _, H0, W0 = frames.shape
     ar.reset()
+    if side_arena is not None:
+        side_arena.reset()
+    text_fork = None
+    if callable(text):
+        text_fork = _Fork(side_stream)
+        with text_fork:
+            text = text()
+    text_hidden, text_pooled = text
     A = ar.alloc
     sc = model._shape_consts(T, H0, W0, dev)
     sizes, lvl_sizes, S, starts = sc["sizes"], sc["lvl_sizes"], sc["S"], sc["starts"]
@@ -36,6 +74,8 @@ def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
     feats = _swin_backbone(model, frames, ar, sizes)
 
     # ------------------------------------------------------------------ text (FeatureResizer :616-635)
+    if text_fork is not None:
+        text_fork.join()
     L = text_hidden.shape[0]
     tmp = _lin(A, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
     text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=A(L, D))
@@ -81,8 +121,9 @@ def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
 
-    def ffn(x, M, pre, l1="linear1", l2="linear2"):
+    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar):
         """x <- x + W2 relu(W1 x) (in place)."""
+        A = ar.alloc
         m1 = ar.mark()
         hdn = A(M, ff)
         gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
@@ -93,8 +134,10 @@ def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
     def ln_(x, pre):
         return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
 
-    def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid):
+    def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
+             ar=ar):
         """resid <- resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src))).  query [T*q_per_frame, D]."""
+        A = ar.alloc
         m1 = ar.mark()
         value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
         proj = A(q_rows, 384)
@@ -155,60 +198,72 @@ def run_clip(model, frames, text_hidden, text_pooled, img_h, img_w, ar):
         ln_(src, lp + "norm2")
     memory = src
 
-    # ------------------------------------------------------------------ decoder (:721-790)
+    # ------------------------------------------------------------------ decoder (:721-790) + heads (:330-365)
     nl = cfg.dec_layers
-    hs = A(nl, T * Q, D)
-    inter_ref = A(nl, T * Q, 4)
-    qpos = w["query_embed.weight"]  # [Q, D], shared by all frames
-    r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
-    init_ref = ops.tile(ops.sigmoid(r, out=A(Q, 2)), T, out=A(T * Q, 2))
-    tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
-    ref, ref_dim = init_ref, 2
-    for lid in range(nl):
-        lp = f"transformer.decoder.layers.{lid}."
-        m0 = ar.mark()
-        pre = lp + "self_attn."
-        qk = A(T * Q, 2 * D)
-        gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
-                sA=Q * D, sA2=0, sC=Q * 2 * D)
-        v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
-        att = A(T * Q, D)
-        if cfg.qtrans:
-            # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
-            ops.mha_core(qk, qk[:, D:], v, Q, NH, T, T, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att, Q * D, D)
-        else:
-            ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
-        gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                ldres=D, res_mode=RES_ADD)
-        ln_(tgt, lp + "norm2")
-        msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt)
-        ln_(tgt, lp + "norm1")
-        ffn(tgt, T * Q, lp)
-        ln_(tgt, lp + "norm3")
-        if cfg.with_box_refine:
-            bp = f"bbox_embed.{lid}.layers."
-            t1 = A(T * Q, D)
-            gemm_ex(tgt, w[bp + "0.weight"], t1, T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
-            t2 = A(T * Q, D)
-            gemm_ex(t1, w[bp + "1.weight"], t2, T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
-            t3 = _lin(A, t2, T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
-            ops.box_refine(t3, ref, out=inter_ref[lid])
-            ref, ref_dim = inter_ref[lid], 4
-        ar.release(m0)
-        ops.tile(tgt, 1, out=hs[lid])
-        if not cfg.with_box_refine:
-            raise NotImplementedError("with_box_refine=False: decoder references stay 2-d; not wired yet")
+    dar = side_arena if side_arena is not None else ar
 
-    # ------------------------------------------------------------------ heads (:330-365)
-    # with box refinement bbox_embed[l] IS transformer.decoder.bbox_embed[l] (tce_rvos.py:124), so
-    # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(ref_{l-1})) is exactly inter_ref[l].
-    logits = A(nl, T * Q, cfg.num_classes)
-    for lvl in range(nl):
-        gemm_ex(hs[lvl], w[f"class_embed.{lvl}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
-                bias=w[f"class_embed.{lvl}.bias"])
+    def decoder_branch():
+        A = dar.alloc
+        nl = cfg.dec_layers
+        hs = A(nl, T * Q, D)
+        inter_ref = A(nl, T * Q, 4)
+        qpos = w["query_embed.weight"]  # [Q, D], shared by all frames
+        r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
+        init_ref = ops.tile(ops.sigmoid(r, out=A(Q, 2)), T, out=A(T * Q, 2))
+        tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
+        ref, ref_dim = init_ref, 2
+        for lid in range(nl):
+            lp = f"transformer.decoder.layers.{lid}."
+            m0 = dar.mark()
+            pre = lp + "self_attn."
+            qk = A(T * Q, 2 * D)
+            gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
+                    sA=Q * D, sA2=0, sC=Q * 2 * D)
+            v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(T * Q, D)
+            if cfg.qtrans:
+                # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
+                ops.mha_core(qk, qk[:, D:], v, Q, NH, T, T, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att, Q * D, D)
+            else:
+                ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
+            gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                    ldres=D, res_mode=RES_ADD)
+            ln_(tgt, lp + "norm2")
+            msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar)
+            ln_(tgt, lp + "norm1")
+            ffn(tgt, T * Q, lp, ar=dar)
+            ln_(tgt, lp + "norm3")
+            if cfg.with_box_refine:
+                bp = f"bbox_embed.{lid}.layers."
+                t1 = A(T * Q, D)
+                gemm_ex(tgt, w[bp + "0.weight"], t1, T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
+                t2 = A(T * Q, D)
+                gemm_ex(t1, w[bp + "1.weight"], t2, T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
+                t3 = _lin(A, t2, T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
+                ops.box_refine(t3, ref, out=inter_ref[lid])
+                ref, ref_dim = inter_ref[lid], 4
+            dar.release(m0)
+            ops.tile(tgt, 1, out=hs[lid])
+            if not cfg.with_box_refine:
+                raise NotImplementedError("with_box_refine=False: decoder references stay 2-d; not wired yet")
+
+        # ------------------------------------------------------------------ heads (:330-365)
+        # with box refinement bbox_embed[l] IS transformer.decoder.bbox_embed[l] (tce_rvos.py:124), so
+        # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(ref_{l-1})) is exactly inter_ref[l].
+        logits = A(nl, T * Q, cfg.num_classes)
+        for lvl in range(nl):
+            gemm_ex(hs[lvl], w[f"class_embed.{lvl}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
+                    bias=w[f"class_embed.{lvl}.bias"])
+
+        return hs, inter_ref, logits
+
+    dec_fork = _Fork(side_stream if side_arena is not None else None)
+    with dec_fork:
+        hs, inter_ref, logits = decoder_branch()
 
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
     mask_feats = _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_)
+    dec_fork.join()
 
     # ------------------------------------------------------------------ dynamic mask head (:371-380, 426-510)
     h4, w4 = sizes[0]

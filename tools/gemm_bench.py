@@ -16,11 +16,23 @@ SHAPES = [  # (M, N, K, count per clip, tag)
 ]
 
 
-def bench(fn, iters=10):
+def bench(fn, iters=10, graph=False):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph:  # GPU-side time of back-to-back launches (host launch cost removed)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
     e0.record()
     for _ in range(iters):
         fn()
