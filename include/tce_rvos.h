@@ -160,6 +160,13 @@ int tce_mask_tail_f32(const float* G, const float* tail, const float* refs /* [n
                       float* masks, int32_t nl, int32_t T, int32_t Q, int32_t h, int32_t w, float img_h, float img_w,
                       int32_t stride_px, tceStream stream);
 
+/* Caller harness H (inference_ytvos.py:238-250, inference_davis.py:239-248) as one kernel: best query =
+ * argmax_q max_k mean_t sigmoid(pred_logits[t,q,k]); that query's mask logits [T,h,w] are bilinearly up-sampled
+ * (align_corners=False) to [T,H0,W0], sigmoid, "> threshold" -> uint8.  best_query (optional) receives the index. */
+int tce_select_masks_u8(const float* logits, const float* masks, uint8_t* out, int32_t* best_query, int32_t T,
+                        int32_t Q, int32_t K, int32_t h, int32_t w, int32_t H0, int32_t W0, float threshold,
+                        tceStream stream);
+
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */
 int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);

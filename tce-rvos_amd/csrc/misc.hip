@@ -108,6 +108,50 @@ __global__ void __launch_bounds__(256) box_refine_kernel(const float* __restrict
   out[i] = 1.f / (1.f + expf(-v));
 }
 
+// ---- caller harness H (inference_ytvos.py:238-250): best query, bilinear up-sampling, sigmoid, threshold ----
+__global__ void __launch_bounds__(256) harness_kernel(const float* __restrict__ logits, const float* __restrict__ masks,
+                                                      uint8_t* __restrict__ out, int* __restrict__ best_out, int T,
+                                                      int Q, int K, int h, int w, int H0, int W0, float threshold) {
+  __shared__ int s_best;
+  if (threadIdx.x == 0) {
+    // pred_scores = sigmoid(logits).mean(frames); max over classes; argmax over queries (first maximum wins)
+    float best = -1.f;
+    int bq = 0;
+    for (int q = 0; q < Q; ++q) {
+      float mx = -1.f;
+      for (int k = 0; k < K; ++k) {
+        float sum = 0.f;
+        for (int t = 0; t < T; ++t) sum += 1.f / (1.f + expf(-logits[((long long)t * Q + q) * K + k]));
+        mx = fmaxf(mx, sum / (float)T);
+      }
+      if (mx > best) {
+        best = mx;
+        bq = q;
+      }
+    }
+    s_best = bq;
+    if (blockIdx.x == 0 && best_out) *best_out = bq;
+  }
+  __syncthreads();
+  const int bq = s_best;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)T * H0 * W0;
+  if (idx >= total) return;
+  const int xo = (int)(idx % W0);
+  const int yo = (int)((idx / W0) % H0);
+  const int t = (int)(idx / ((long long)W0 * H0));
+  const float sy = (float)h / (float)H0, sx = (float)w / (float)W0;
+  const float fy = fmaxf(sy * ((float)yo + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(sx * ((float)xo + 0.5f) - 0.5f, 0.f);
+  const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* m = masks + ((long long)t * Q + bq) * h * w;
+  const float v = hy * (hx * m[y0 * w + x0] + lx * m[y0 * w + x1]) + ly * (hx * m[y1 * w + x0] + lx * m[y1 * w + x1]);
+  out[idx] = (1.f / (1.f + expf(-v)) > threshold) ? 1 : 0;
+}
+
 // ---- dynamic mask head -------------------------------------------------------------------------------
 constexpr int DC = 8;        // dynamic_mask_channels
 constexpr int TAIL_LD = 112;  // floats per (level, frame, query) in the packed tail parameter block
@@ -245,6 +289,18 @@ extern "C" int tce_box_refine_f32(const float* tmp, const float* ref, float* out
   hipLaunchKernelGGL(box_refine_kernel, dim3(tce_cdiv(n * 4, 256)), dim3(256), 0, (hipStream_t)stream, tmp, ref, out, n,
                      ref_dim);
   TCE_CHECK_LAUNCH("tce_box_refine_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_select_masks_u8(const float* logits, const float* masks, uint8_t* out, int32_t* best_query,
+                                   int32_t T, int32_t Q, int32_t K, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                                   float threshold, tceStream stream) {
+  TCE_CHECK_ARG(logits && masks && out && T > 0 && Q > 0 && K > 0 && h > 0 && w > 0 && H0 > 0 && W0 > 0,
+                "tce_select_masks_u8: bad arguments");
+  const long long total = (long long)T * H0 * W0;
+  hipLaunchKernelGGL(harness_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, masks, out,
+                     best_query, T, Q, K, h, w, H0, W0, threshold);
+  TCE_CHECK_LAUNCH("tce_select_masks_u8");
   return TCE_OK;
 }
 

@@ -364,3 +364,19 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
     g.sA, g.sA2, g.sW, g.sBias, g.sC, g.sRes = sA, sA2, sW, sBias, sC, sRes
     _gemm_launch(g)
     return out
+
+
+def select_masks(pred_logits, pred_masks, out_hw, threshold=0.5):
+    """Caller harness H (inference_ytvos.py:238-250) on the GPU: pred_logits [T,Q,K], pred_masks [T,Q,h,w]
+    -> (uint8 masks [T,H0,W0], best-query index tensor [1] int32)."""
+    _chk(pred_logits, "pred_logits")
+    _chk(pred_masks, "pred_masks")
+    T, Q, K = pred_logits.shape
+    _, _, h, w = pred_masks.shape
+    H0, W0 = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty(T, H0, W0, dtype=torch.uint8, device=pred_masks.device)
+    best = torch.empty(1, dtype=torch.int32, device=pred_masks.device)
+    check(lib().tce_select_masks_u8(pred_logits.contiguous().data_ptr(), pred_masks.contiguous().data_ptr(),
+                                    out.data_ptr(), best.data_ptr(), T, Q, K, h, w, H0, W0, float(threshold), _stream()),
+          "tce_select_masks_u8")
+    return out, best

@@ -115,3 +115,28 @@ def test_video_swin_t_small_matches_reference(models):
     """Video-Swin-T backbone, T=9 (> window depth 8: temporal padding + temporal shift path)."""
     fx, out, _ = _run(models, "e2e_vswin_t_small.npz", "video_swin_t_p4w7")
     _compare(out, fx, 5e-3)
+
+
+@pytest.mark.parametrize("backbone,T,H,W", [("video_swin_t_p4w7", 8, 384, 640),   # BASELINE config 3
+                                            ("swin_b_p4w7", 10, 480, 854)])      # BASELINE config 5 (fp16 MFMA, f32 acc)
+def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
+    """BASELINE configs 3 and 5 at full size: HIP path vs the CPU oracle (itself pinned to the reference by the
+    golden fixtures) on the same synthetic weights / inputs."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    model = models(backbone, 11)
+    frames = synth_frames(T, H, W, 123)
+    g = torch.Generator().manual_seed(7)
+    hid = torch.randn(32, 768, generator=g)
+    pooled = torch.tanh(torch.randn(768, generator=g))
+    out = model.forward_features(frames.cuda(), hid.cuda(), pooled.cuda(), float(H), float(W))
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    b = __import__("tce_rvos_amd.config", fromlist=["BACKBONES"]).BACKBONES[backbone]
+    cfg = O.OracleConfig(backbone=backbone, embed_dim=b["embed_dim"], depths=b["depths"], num_heads=b["num_heads"])
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, frames, hid[None], pooled[None], img_size=(H, W))
+    diffs = {k: (out[k].cpu() - ref[k]).abs().max().item() for k in ("pred_logits", "pred_boxes", "pred_masks")}
+    iou = O.mask_iou(out["pred_masks"].cpu() > 0, ref["pred_masks"] > 0)
+    print(backbone, "max abs diffs vs oracle:", diffs, "IoU", iou)
+    assert diffs["pred_logits"] < 5e-3 and diffs["pred_boxes"] < 2e-4 and diffs["pred_masks"] < 5e-2
+    assert iou > 1 - 1e-3

@@ -361,3 +361,14 @@ def test_window_attention_3d(ops, T, H, W, nH, shifted):
     out = ops.window_attn3d(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
                             C, nH, shifted)
     close(out, ref, 1e-4, 1e-4)
+
+
+def test_harness_select_masks_matches_reference_caller(ops):
+    """tce_select_masks_u8 against the reference caller's outputs (golden harness_cases.npz)."""
+    fx = load_npz("harness_cases.npz")
+    for i in range(int(fx["n_cases"])):
+        size = tuple(int(v) for v in fx[f"h{i}_size"])
+        m, best = ops.select_masks(dev(torch.from_numpy(fx[f"h{i}_logits"])[0]), dev(torch.from_numpy(fx[f"h{i}_masks"])[0]), size)
+        assert int(best.item()) == int(fx[f"h{i}_best"])
+        ref = torch.from_numpy(fx[f"h{i}_out"])
+        assert O.mask_iou(m.cpu().bool(), ref) > 1 - 1e-4
