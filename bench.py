@@ -29,6 +29,18 @@ if ROOT not in sys.path:
 METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
 
 
+def _pmc_traffic(prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc passes of
+    this same command: profiles/r01_pmc_traffic.json).  None when no summary matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        hits = [v for name, v in k.items() if name.startswith(prefix) and ", false, false" in name]
+        return round(hits[0]["hbm_bytes_per_launch"]) if hits else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,7 +143,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": f"{kname}<{tname},{'true' if key[1] else 'false'}>", "gemm_mode": mode,
                     "mfma_issued_tflops": round(ach * (1 if mode == "f32" else 3), 2),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": n // args.steps,
+                    "traffic": _pmc_traffic(f"{kname}<{tname.replace(',', ', ')}"), "launches_per_step": n // args.steps,
                     "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
                     "all_gemm_ms_per_step": round(gemm_sec_per_step * 1e3, 3),
                     "all_gemm_tflops": round(sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12, 2)}

@@ -56,6 +56,8 @@ int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int3
 /* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
  * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
 int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
+/* diagnostic: register (or clear with NULL) a device buffer of >= 2048*8 int64 for in-kernel s_memtime stamps */
+int tce_debug_set_stamp_buffer(long long* dev_buf);
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 

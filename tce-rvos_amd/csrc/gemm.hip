@@ -159,22 +159,20 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, cons
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
   // --- epilogue
-#define EPI_BODY(ACT, RES)                                                                                       \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
-    const int col = tn * BN + wn * WN + j * 32 + l31;                                                            \
-    if (col < p.N) {                                                                                             \
-      const float bv = bias ? bias[col] : 0.f;                                                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
-          tce_epi_store<ACT, RES>(acc[i][j], bv, res, C, tm * BM + wm * WM + i * 32 + 4 * lhi, col, p.M, p.ldc,  \
-                                  p.ldres);                                                                      \
-    }                                                                                                            \
+  const bool vec_ok = tce_epi_vec_ok(C, p.ldc, res, p.ldres, bias, p.res_mode);
+#define EPI_BODY(ACT, RES)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                \
+    const int row = tm * BM + wm * WM + i * 32 + l31;                                                             \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                \
+        tce_epi_store_t<ACT, RES>(acc[i][j], bias, res, C, row, tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N,   \
+                                  p.ldc, p.ldres, vec_ok);                                                        \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
 #undef EPI_BODY
@@ -195,6 +193,7 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 
 int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3.hip
 bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s);        // gemm_f16x3.hip
+extern int g_pc_ablate;
 
 static int g_gemm_mode = 1;  // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate)
 
@@ -209,6 +208,12 @@ extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
 static int g_force_tile = 0;
 extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile (tuning aid)
+  if (tile == 1001 || tile == 1002) {  // ablation builds of the producer/consumer kernel (timing only, wrong results)
+    g_pc_ablate = tile - 1000;
+    g_force_tile = 1;
+    return TCE_OK;
+  }
+  g_pc_ablate = 0;
   TCE_CHECK_ARG(tile == 0 || tile == 1 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465 || tile == 256129 || tile == 256130 || tile == 12865,
                 "tce_gemm_force_tile: bad tile (1 = persistent producer/consumer kernel where applicable)");
   g_force_tile = tile;

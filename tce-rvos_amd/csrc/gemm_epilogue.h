@@ -29,6 +29,65 @@ __device__ __forceinline__ void tce_epi_store(const f32x16& x, const float bv, c
   }
 }
 
+// Transposed-accumulator form (the GEMM kernels issue mfma(W_frag, A_frag): D[i = n][j = m]): the lane owns output
+// ROW m and accumulator registers 4g..4g+3 are 4 CONSECUTIVE columns n0 + 8g + (0..3)  (n0 already includes
+// 4*(lane>>5)), so a 32x32 tile is written with four 16-byte stores per lane instead of sixteen 4-byte ones
+// (dword-per-lane epilogues are store-issue bound at ~7 B/clk/CU on gfx950: this cut the epilogue of a
+// 256x128 tile from 17k to a few thousand cycles).  vec_ok = row pitches / bases allow aligned float4 access.
+template <int ACT, int RES>
+__device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __restrict__ bias,
+                                                const float* __restrict__ res, float* __restrict__ C, const int row,
+                                                const int n0, const int M, const int N, const long long ldc,
+                                                const long long ldres, const bool vec_ok) {
+  if (row >= M) return;
+  float* crow = C + (long long)row * ldc;
+  const float* rrow = (RES != 0) ? res + (long long)row * ldres : nullptr;
+  if (vec_ok && n0 + 27 < N) {
+    f32x4 rv[4], bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (RES != 0) rv[g] = *reinterpret_cast<const f32x4*>(rrow + n0 + 8 * g);
+      if (bias) bv[g] = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = x[4 * g + c] + (bias ? bv[g][c] : 0.f);
+        if (ACT == 1) v = fmaxf(v, 0.f);
+        if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (RES == 1) v += rv[g][c];
+        if (RES == 2) v *= rv[g][c];
+        o[c] = v;
+      }
+      *reinterpret_cast<f32x4*>(crow + n0 + 8 * g) = o;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int n = n0 + 8 * g + c;
+        if (n < N) {
+          float v = x[4 * g + c] + (bias ? bias[n] : 0.f);
+          if (ACT == 1) v = fmaxf(v, 0.f);
+          if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+          if (RES == 1) v += rrow[n];
+          if (RES == 2) v *= rrow[n];
+          crow[n] = v;
+        }
+      }
+  }
+}
+
+__device__ __forceinline__ bool tce_epi_vec_ok(const float* C, long long ldc, const float* res, long long ldres,
+                                               const float* bias, int res_mode) {
+  bool ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15u) == 0) && (!bias || ((((uintptr_t)bias) & 15u) == 0));
+  if (res_mode != 0) ok = ok && ((ldres & 3) == 0) && ((((uintptr_t)res) & 15u) == 0);
+  return ok;
+}
+
 // runs BODY(ACT, RES) with compile-time constants chosen from the run-time (act, res_mode)
 #define TCE_EPI_DISPATCH(act, res_mode, BODY) \
   switch ((act) * 3 + (res_mode)) {           \

@@ -57,6 +57,11 @@ __device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo
   lo.b = __builtin_amdgcn_cvt_pkrtz(d2, d3);
 }
 
+// Diagnostic stamps (tce_debug_set_stamp_buffer): when a buffer is registered, lane 0 of wave 0 of the first 2048
+// workgroups of the symmetric kernel records s_memtime at entry / after the prologue / after the K loop / after
+// the epilogue stores were issued / after they drained.  NULL (the default) costs one uniform branch.
+__device__ long long* g_stamp_buf = nullptr;
+
 // Symmetric kernel: every wave loads, converts and multiplies.  DEPTH K-slices are kept in flight per thread in a
 // register ring (loads are unconditional -- clamped addresses, validity applied at commit -- and the steady-state
 // loop is branch-free, so the compiler emits exact counted vmcnt waits): a K step no longer pays a full memory
@@ -81,6 +86,8 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int bz = blockIdx.z;
+  long long* const stamps = (g_stamp_buf && blockIdx.x < 2048 && tid == 0) ? g_stamp_buf + blockIdx.x * 8 : nullptr;
+  if (stamps) stamps[0] = (long long)__builtin_amdgcn_s_memtime();
 
   const float* __restrict__ A = p.A + (long long)bz * p.sA;
   const float* __restrict__ A2 = HAS_A2 ? p.A2 + (long long)bz * p.sA2 : nullptr;
@@ -209,9 +216,10 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+          // operands swapped: D[n][m] -- the lane owns an output row (see tce_epi_store_t)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acx[i][j], 0, 0, 0);
         }
     }
   };
@@ -222,6 +230,7 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   commit(ra[0], rb[0], ra2[0], okm[0], 0);
   issue(ra[0], rb[0], ra2[0], okm[0], DEPTH);
   __syncthreads();
+  if (stamps) stamps[1] = (long long)__builtin_amdgcn_s_memtime();
   int kt0 = 0;
   for (; kt0 + DEPTH <= nk; kt0 += DEPTH) {
 #pragma unroll
@@ -244,22 +253,27 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
       __syncthreads();
     }
   }
+  if (stamps) stamps[2] = (long long)__builtin_amdgcn_s_memtime();
 
+  const bool vec_ok = tce_epi_vec_ok(C, p.ldc, res, p.ldres, bias, p.res_mode);
 #define EPI_BODY(ACT, RES)                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
-    const int col = tn * BN + wn * WN + j * 32 + l31;                                                       \
-    if (col < p.N) {                                                                                        \
-      const float bv = bias ? bias[col] : 0.f;                                                              \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                      \
-        f32x16 x;                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) x[r] = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]);     \
-        tce_epi_store<ACT, RES>(x, bv, res, C, tm * BM + wm * WM + i * 32 + 4 * lhi, col, p.M, p.ldc,       \
-                                p.ldres);                                                                   \
-      }                                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
+    const int row = tm * BM + wm * WM + i * 32 + l31;                                                       \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                        \
+      f32x16 x;                                                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) x[r] = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]);       \
+      tce_epi_store_t<ACT, RES>(x, bias, res, C, row, tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N,       \
+                                p.ldc, p.ldres, vec_ok);                                                    \
     }                                                                                                       \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
 #undef EPI_BODY
+  if (stamps) {
+    stamps[3] = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamps[4] = (long long)__builtin_amdgcn_s_memtime();
+    stamps[5] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <int BM, int BN, int WAVES_M, int DEPTH>
@@ -313,7 +327,7 @@ constexpr int PC_BM = 128, PC_BN = 128;
 
 template <bool CONV, bool HAS_A2>
 __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n,
-                                                              const int total_tiles) {
+                                                              const int total_tiles, const int ablate) {
   constexpr int BM = PC_BM, BN = PC_BN;
   constexpr int PC_DEPTH = HAS_A2 ? 3 : 4;  // slices in flight per producer thread (register ring)
   constexpr int PLANE = BM * 64;  // bytes (BM == BN)
@@ -443,8 +457,10 @@ __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs
 #pragma unroll
       for (int d = 0; d < PC_DEPTH; ++d) {
         const int r = (d + 1) % PC_DEPTH;  // ring slot holding slice s+1
-        commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (int)((s0 + d + 1) & 1));
-        issue(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r]);  // slice s+1+DEPTH
+        if (ablate != 2) {
+          commit(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r], (int)((s0 + d + 1) & 1));
+          issue(ra[r], rb[r], ra2[HAS_A2 ? r : 0], okm[r]);  // slice s+1+DEPTH
+        }
         __syncthreads();
       }
     }
@@ -476,6 +492,7 @@ __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs
   int tj = 0, kt = 0;
   for (long long s = 0; s < nsteps; ++s) {
     const unsigned char* st = smem + (int)(s & 1) * STAGE;
+    if (ablate != 1)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = ks * 2 + lhi;
@@ -493,9 +510,10 @@ __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+          // operands swapped: D[n][m] -- the lane owns an output row (see tce_epi_store_t)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acx[i][j], 0, 0, 0);
         }
     }
     if (++kt == nk) {
@@ -506,20 +524,19 @@ __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs
       const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
       const float* __restrict__ res = p.res ? p.res + (long long)bz * p.sRes : nullptr;
       float* __restrict__ C = p.C + (long long)bz * p.sC;
+      const bool vec_ok = tce_epi_vec_ok(C, p.ldc, res, p.ldres, bias, p.res_mode);
 #define EPI_BODY(ACT, RES)                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
-    const int col = tn * BN + wn * 64 + j * 32 + l31;                                                       \
-    const bool cok = col < p.N;                                                                             \
-    const float bv = (bias && cok) ? bias[col] : 0.f;                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+    const int row = tm * BM + wm * 64 + i * 32 + l31;                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
       f32x16 x;                                                                                             \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
         x[r] = fmaf(acx[i][j][r], LO_INV, acc[i][j][r]);                                                    \
         acc[i][j][r] = 0.f;                                                                                 \
         acx[i][j][r] = 0.f;                                                                                 \
       }                                                                                                     \
-      if (cok) tce_epi_store<ACT, RES>(x, bv, res, C, tm * BM + wm * 64 + i * 32 + 4 * lhi, col, p.M, p.ldc, \
-                                       p.ldres);                                                            \
+      tce_epi_store_t<ACT, RES>(x, bias, res, C, row, tn * BN + wn * 64 + j * 32 + 4 * lhi, p.M, p.N,       \
+                                p.ldc, p.ldres, vec_ok);                                                    \
     }                                                                                                       \
   }
       TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
@@ -534,6 +551,7 @@ __global__ void __launch_bounds__(512, 1) gemm_f16x3_pc_kernel(const tceGemmArgs
 }  // namespace
 
 // persistent producer/consumer launch; returns false if the problem is too small to fill the chip this way
+int g_pc_ablate = 0;  // tuning aid: 1 = consumers skip the MFMAs, 2 = producers skip loads/conversion
 bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, PC_BM), tiles_n = tce_cdiv(a.N, PC_BN);
   const long long total = (long long)tiles_m * tiles_n * (a.batch > 0 ? a.batch : 1);
@@ -548,10 +566,19 @@ bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s) {
   }
   const int G = (int)((total < n_cu) ? ((total + 7) & ~7LL) : n_cu);
   if (a.conv)
-    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<true, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<true, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total, g_pc_ablate);
   else if (a.A2)
-    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, true>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, true>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total, g_pc_ablate);
   else
-    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total);
+    hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total, g_pc_ablate);
   return true;
+}
+
+extern "C" int tce_debug_set_stamp_buffer(long long* dev_buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dev_buf, sizeof(dev_buf));
+  if (e != hipSuccess) {
+    tce_set_error("tce_debug_set_stamp_buffer: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  return TCE_OK;
 }
