@@ -276,9 +276,12 @@ class ReferFormer(nn.Module):
 
     # ---------------------------------------------------------------- the boundary
     @torch.no_grad()
-    def forward(self, samples, captions, targets):
+    def forward(self, samples, captions, targets, slot=0):
         """models/tce_rvos.py:194.  samples: NestedTensor([B,T,3,H,W],[B,T,H,W]) or list of [T,3,H,W];
-        captions: list[str] (or a LongTensor [B,L] of token ids); targets: list[dict] with 'size'."""
+        captions: list[str] (or a LongTensor [B,L] of token ids); targets: list[dict] with 'size'.
+        slot (extension, default 0): independent replay resources (graph, arenas, static inputs).  Clips are
+        independent units, so a caller may keep several B=1 forwards in flight on different torch streams
+        (one slot per stream) to fill the GPU; each forward is still exactly the B=1 computation."""
         if not isinstance(samples, NestedTensor) and not (hasattr(samples, "tensors") and hasattr(samples, "mask")):
             if len(samples) == 1:  # a single clip is never padded: no copy, no mask, no host sync
                 vids, mask = samples[0][None], None
@@ -315,7 +318,7 @@ class ReferFormer(nn.Module):
             return self._run(frames, (hid[0].contiguous(), pooled[0].contiguous()), img_h, img_w, None)
         # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder beside
         # the pixel decoder
-        key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training)
+        key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot))
         ent = self._graphs.get(key)
         if ent is None:
             st = (frames.clone(), ids.clone(), att.clone())
