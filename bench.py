@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (+ TCE_BENCH_ONE_DEVICE=1: every rank on cuda:0) rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent B=1 clip forwards kept in flight per GPU and per step (one stream + replay slot each)")
     args = ap.parse_args()
@@ -67,10 +69,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if os.environ.get("TCE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks
@@ -94,7 +101,7 @@ def main():
     C = max(1, args.clips_in_flight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(C)] if C > 1 else None
 
-    def step(i):
+    def step(i, gather=True):
         nonlocal gather_buf
         if C == 1:
             out = model([clips[i % n_pool]], ids[i % n_pool], targets)
@@ -110,8 +117,8 @@ def main():
                 cur.wait_stream(streams[c])
             out = outs[0]
             local = torch.cat([o["pred_masks"] for o in outs], 0)
-        if world > 1:  # the masks of all world*C clips of this step meet on every rank
-            gather_buf = gather_clip_masks(local, world * C)
+        if world > 1 and gather:  # the masks of all world*C clips of this step meet on every rank
+            gather_buf = gather_clip_masks(local if args.backend == "nccl" else local.cpu(), world * C)
         return out
 
     def fence():
@@ -128,7 +135,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -136,10 +143,10 @@ def main():
     C_saved, C = C, 1  # the instrumented pass and the parity check run one clip at a time
     if rank == 0 and not args.no_roofline:
         graph_mode, model.use_graph = model.use_graph, False  # per-launch events need eager launches
-        step(0)
+        step(0, gather=False)  # rank-0-only passes must not enter the collective
         ops.GEMM_PROFILE = []
         for i in range(args.steps):
-            step(i)
+            step(i, gather=False)
         torch.cuda.synchronize()
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         model.use_graph = graph_mode
@@ -186,7 +193,7 @@ def main():
         cpu_baseline = {"value": round(1.0 / times[-1], 4), "unit": "clips/s", "cores": cores, "kind": "port",
                         "sample": f"1 clip (T={T}, {H}x{W}, {args.tokens} tokens), 2nd of 2 oracle forwards, "
                                   f"{times[-1]:.2f} s; text encoder excluded"}
-        out = step(0)
+        out = step(0, gather=False)
         torch.cuda.synchronize()
         pm = out["pred_masks"].cpu()
         parity = {"mask_iou_vs_oracle": round(O.mask_iou(pm > 0, ref["pred_masks"] > 0), 6),

@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256) window_attn_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) mha_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O, int nheads,
                                                        int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
                                                        long long sK, long long sV, long long sO,
@@ -200,22 +201,39 @@ __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m = -3.0e38f, l = 0.f;  // l is this lane-half's partial sum
+  // K/V tiles are double-buffered through registers: the next tile's global loads are issued before the MFMAs
+  // of the current one, so a key tile no longer costs a full memory round trip (with one wave per workgroup
+  // nothing else on the CU hides it).
+  constexpr int NLD = 256 / (64 * NW);  // float4 pairs per thread per tile
+  f32x4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + u * 64 * NW;
+      const int j = i >> 3, d4 = i & 7;
+      const int kk = min(k0 + j, Lk - 1);  // clamped: rows past the end are masked by sM
+      kreg[u] = *reinterpret_cast<const f32x4*>(Kb + (long long)kk * ldk + d4 * 4);
+      vreg[u] = *reinterpret_cast<const f32x4*>(Vb + (long long)kk * ldv + d4 * 4);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < Lk; k0 += KT) {
     const int kn = min(KT, Lk - k0);
     __syncthreads();
-    for (int i = tid; i < KT * 8; i += nthr) {
-      const int j = i >> 3, d4 = i & 7;
-      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (j < kn) {
-        kv = *reinterpret_cast<const f32x4*>(Kb + (long long)(k0 + j) * ldk + d4 * 4);
-        vv = *reinterpret_cast<const f32x4*>(Vb + (long long)(k0 + j) * ldv + d4 * 4);
-      }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sK_[j * KP + d4 * 4 + c] = kv[c];
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + u * 64 * NW;
+      const int j = i >> 3, d4 = i & 7;
+      const bool ok = j < kn;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sK_[j * KP + d4 * 4 + c] = ok ? kreg[u][c] : 0.f;
+      f32x4 vv = vreg[u];
+      if (!ok) vv = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&sV_[j * HD + d4 * 4]) = vv;
     }
     for (int j = tid; j < KT; j += nthr)
       sM[j] = (j < kn && !(kmask && kmask[(long long)b * Lk + k0 + j])) ? 0.f : -3.0e38f;
+    if (k0 + KT < Lk) fetch(k0 + KT);
     __syncthreads();
     // S^T[key][q] : A = K[key = l31][d = 2s + lhi], B = qreg[s]
     f32x16 st;
@@ -444,8 +462,12 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
   const long long tiles = (long long)tce_cdiv(Lq, 32) * batch * nheads;
   const int nw = (tiles >= 4096) ? 4 : 1;
   dim3 grid(tce_cdiv(Lq, 32 * nw), batch * nheads);
-  hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(64 * nw), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
-                     ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
+  if (nw == 4)
+    hipLaunchKernelGGL(mha_mfma_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
+                       ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
+  else
+    hipLaunchKernelGGL(mha_mfma_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
+                       ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
   TCE_CHECK_LAUNCH("tce_mha_f32");
   return TCE_OK;
 }
