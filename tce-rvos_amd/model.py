@@ -105,6 +105,10 @@ class ReferFormer(nn.Module):
             node.register_buffer(leaf, self._rel_index(cfg))
         if cfg.with_box_refine:  # one tensor, two names (tce_rvos.py:124)
             self.transformer.decoder.add_module("bbox_embed", self.bbox_embed)
+        else:  # one head listed under every level's name (tce_rvos.py:127-130)
+            for i in range(1, cfg.dec_layers):
+                self.class_embed.add_module(str(i), self.class_embed._modules["0"])
+                self.bbox_embed.add_module(str(i), self.bbox_embed._modules["0"])
         if text_encoder is None:
             text_encoder = build_text_encoder(args)
         self.text_encoder = text_encoder

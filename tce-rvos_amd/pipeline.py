@@ -244,22 +244,32 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                 ref, ref_dim = inter_ref[lid], 4
             dar.release(m0)
             ops.tile(tgt, 1, out=hs[lid])
-            if not cfg.with_box_refine:
-                raise NotImplementedError("with_box_refine=False: decoder references stay 2-d; not wired yet")
 
         # ------------------------------------------------------------------ heads (:330-365)
         # with box refinement bbox_embed[l] IS transformer.decoder.bbox_embed[l] (tce_rvos.py:124), so
         # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(ref_{l-1})) is exactly inter_ref[l].
         logits = A(nl, T * Q, cfg.num_classes)
         for lvl in range(nl):
-            gemm_ex(hs[lvl], w[f"class_embed.{lvl}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
-                    bias=w[f"class_embed.{lvl}.bias"])
-
-        return hs, inter_ref, logits
+            ci = lvl if cfg.with_box_refine else 0  # without refinement one head is shared by all levels (:127-130)
+            gemm_ex(hs[lvl], w[f"class_embed.{ci}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
+                    bias=w[f"class_embed.{ci}.bias"])
+        if cfg.with_box_refine:
+            return hs, inter_ref, inter_ref, 4, logits
+        # no refinement: every layer saw the initial 2-d reference points; boxes come from the shared bbox_embed
+        # applied to each level's hs (+ inverse_sigmoid(ref) on xy), tce_rvos.py:330-349
+        refs2 = ops.tile(init_ref, nl, out=A(nl, T * Q, 2))
+        bp = "bbox_embed.0.layers."
+        t1 = A(nl * T * Q, D)
+        gemm_ex(hs, w[bp + "0.weight"], t1, nl * T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
+        t2 = A(nl * T * Q, D)
+        gemm_ex(t1, w[bp + "1.weight"], t2, nl * T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
+        t3 = _lin(A, t2, nl * T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
+        ops.box_refine(t3, refs2, out=inter_ref)
+        return hs, inter_ref, refs2, 2, logits
 
     dec_fork = _Fork(side_stream if side_arena is not None else None)
     with dec_fork:
-        hs, inter_ref, logits = decoder_branch()
+        hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
 
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
     mask_feats = _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_)
@@ -282,21 +292,21 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     G = A(T, h4 * w4, nl * Q * 8)
     ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
     masks = A(nl, T, Q, h4, w4)
-    ops.mask_tail(G, tail, inter_ref, 4, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
+    ops.mask_tail(G, tail, mask_refs, ref_ld, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
 
     # ------------------------------------------------------------------ output dict (:360-393); leave the arena
     K = cfg.num_classes
     out = {
         "pred_logits": logits[-1].reshape(1, T, Q, K).clone(),
-        "pred_boxes": inter_ref[-1].reshape(1, T, Q, 4).clone(),
+        "pred_boxes": boxes[-1].reshape(1, T, Q, 4).clone(),
         "pred_masks": masks[-1].reshape(1, T, Q, h4, w4).clone(),
     }
     if cfg.aux_loss:
         out["aux_outputs"] = [{"pred_logits": logits[i].reshape(1, T, Q, K).clone(),
-                               "pred_boxes": inter_ref[i].reshape(1, T, Q, 4).clone(),
+                               "pred_boxes": boxes[i].reshape(1, T, Q, 4).clone(),
                                "pred_masks": masks[i].reshape(1, T, Q, h4, w4).clone()} for i in range(nl - 1)]
     if not model.training:
-        out["reference_points"] = inter_ref[-2].reshape(1, T, Q, 4)[..., :2].clone()
+        out["reference_points"] = mask_refs[-2].reshape(1, T, Q, ref_ld)[..., :2].clone()
     out["memory"] = memory.reshape(T, S, D).clone()
     ar.release(m0)
     return out

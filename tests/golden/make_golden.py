@@ -16,7 +16,8 @@ Fixtures
                        frames = randn(seed); text encoder outputs stored (third-party RoBERTa, random init)
   e2e_vswin_t_small.npz same with Video-Swin-T, T=9 (> window depth 8: temporal shift path)
   e2e_swin_t_cfg2.npz  BASELINE config 2 at full size (T=5, 360x640): outputs only
-  statedict_*.json     the reference's state-dict keys/shapes (the drop-in checkpoint contract)
+  statedict_*.json     the reference's state-dict keys/shapes (the drop-in checkpoint contract); *_plain = without
+                       --with_box_refine/--f_token/--qtrans
   harness_cases.npz    caller harness H (inference_ytvos.py:238-250): logits+masks -> thresholded mask
 """
 import os
@@ -147,6 +148,16 @@ def gen_statedict_manifest(model, name):
         json.dump(man, f, indent=0, sort_keys=True)
 
 
+def gen_plain_manifest():
+    """State-dict contract of the reference WITHOUT --with_box_refine / --f_token / --qtrans (shared heads are listed
+    under every level's name, no decoder.bbox_embed alias, no frame-token parameters)."""
+    import opts
+    args = opts.get_args_parser().parse_args(["--binary", "--freeze_text_encoder", "--backbone", "swin_t_p4w7"])
+    args.masks, args.device = True, "cpu"
+    model = rh.build_reference_model(args, roberta_layers=1)
+    gen_statedict_manifest(model, "statedict_swin_t_plain.json")
+
+
 def gen_harness():
     """inference_ytvos.py:238-250 restated with the same PyTorch primitives the caller uses."""
     torch.manual_seed(21)
@@ -184,4 +195,5 @@ if __name__ == "__main__":
     gen_statedict_manifest(m, "statedict_vswin_t.json")
     # BASELINE config 2 at full size: only the outputs are kept (inputs/weights regenerate from seeds)
     gen_e2e("e2e_swin_t_cfg2.npz", "swin_t_p4w7", T=5, H=360, W=640, seed=4, store_stages=False)
+    gen_plain_manifest()
     print("done")

@@ -140,3 +140,36 @@ def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
     print(backbone, "max abs diffs vs oracle:", diffs, "IoU", iou)
     assert diffs["pred_logits"] < 5e-3 and diffs["pred_boxes"] < 2e-4 and diffs["pred_masks"] < 5e-2
     assert iou > 1 - 1e-3
+
+
+@pytest.mark.parametrize("flags", [dict(with_box_refine=False, qtrans=True, f_token=8),
+                                   dict(with_box_refine=True, qtrans=False, f_token=0),
+                                   dict(with_box_refine=False, qtrans=False, f_token=3, aux_loss=False)])
+def test_flag_combinations_match_oracle(flags):
+    """The reference's model-variation flags (opts.py:25,78,148,153): box refinement on/off, IQT on/off, frame tokens
+    0 / 3 / 8, aux outputs on/off -- HIP path vs oracle on the same weights."""
+    from tce_rvos_amd import build_model
+    ns = _args("swin_t_p4w7")
+    for k, v in flags.items():
+        setattr(ns, k, v)
+    model, _, _ = build_model(ns)
+    model = model.cuda().eval()
+    T, H, W = 3, 80, 120
+    frames = synth_frames(T, H, W, 5)
+    g = torch.Generator().manual_seed(3)
+    hid, pooled = torch.randn(9, 768, generator=g), torch.tanh(torch.randn(768, generator=g))
+    out = model.forward_features(frames.cuda(), hid.cuda(), pooled.cuda(), float(H), float(W))
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    cfg = O.OracleConfig(with_box_refine=flags.get("with_box_refine", True), qtrans=flags.get("qtrans", True),
+                         f_token=flags.get("f_token", 8), aux_loss=flags.get("aux_loss", True))
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, frames, hid[None], pooled[None], img_size=(H, W))
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("pred_masks", 5e-3), ("reference_points", 1e-4)):
+        d = (out[k].cpu() - ref[k]).abs().max().item()
+        assert d < tol, (flags, k, d)
+    assert ("aux_outputs" in out) == flags.get("aux_loss", True)
+    if "aux_outputs" in out:
+        for a, b in zip(out["aux_outputs"], ref["aux_outputs"]):
+            assert (a["pred_boxes"].cpu() - b["pred_boxes"]).abs().max().item() < 1e-4
+            assert (a["pred_masks"].cpu() - b["pred_masks"]).abs().max().item() < 5e-3

@@ -90,6 +90,20 @@ def test_model_state_dict_contract_and_build_model_boundary():
         model([torch.zeros(2, 3, 32, 32)], ["a"], [{"size": torch.tensor([32, 32])}])  # CPU input: no CPU path
 
 
+def test_plain_flags_state_dict_contract():
+    """Without --with_box_refine / --f_token / --qtrans the reference lists its shared heads under every level's
+    name and has no frame-token parameters: same keys and shapes here."""
+    import argparse
+    from tce_rvos_amd import build_model
+    model, _, _ = build_model(argparse.Namespace(backbone="swin_t_p4w7", with_box_refine=False, binary=True, f_token=0,
+                                                 qtrans=False, text_encoder_layers=1))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "statedict_swin_t_plain.json")))
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    assert set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k][0]) for k in ref)
+    assert model.class_embed._modules["3"] is model.class_embed._modules["0"]
+
+
 def test_unsupported_configs_fail_loudly():
     import argparse
     from tce_rvos_amd import build_model
