@@ -169,6 +169,16 @@ int tce_select_masks_u8(const float* logits, const float* masks, uint8_t* out, i
                         int32_t Q, int32_t K, int32_t h, int32_t w, int32_t H0, int32_t W0, float threshold,
                         tceStream stream);
 
+/* RoBERTa text encoder (models/tce_rvos.py:406-424; HuggingFace RobertaModel arithmetic) -- the pieces not covered
+ * by tce_gemm_f32 / tce_layernorm_f32:
+ *   tce_embed_ln_f32     out[t] = LayerNorm(word[ids[t]] + position[pos_ids[t]] + token_type[0])   (ids int64, device)
+ *   tce_mha_small64_f32  self-attention core over packed qkv [L, 3*nheads*64] (head_dim 64, L <= 128) -> [L, nheads*64]
+ *   tce_tanh_f32         pooler activation */
+int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                     const float* gamma, const float* beta, float* out, int32_t L, int32_t C, float eps, tceStream stream);
+int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int32_t nheads, float scale, tceStream stream);
+int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
+
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */
 int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);

@@ -54,6 +54,9 @@ SIGNATURES = {
     "tce_mask_pack_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_mask_tail_f32": (i32, [c_f, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, f32, f32, i32, c_f]),
     "tce_select_masks_u8": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, f32, c_f]),
+    "tce_embed_ln_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, f32, c_f]),
+    "tce_mha_small64_f32": (i32, [c_f, c_f, i32, i32, f32, c_f]),
+    "tce_tanh_f32": (i32, [c_f, c_f, i64, c_f]),
     "tce_graph_begin": (i32, [c_f]),
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),

@@ -81,6 +81,75 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
   }
 }
 
+// LDS-staged form of the same epilogue: the wave parks its 32x32 accumulator tile (row-per-lane layout) in a private
+// 32 x 36-float LDS buffer and reads it back with 8 lanes per row, so every global store / residual load instruction
+// covers 8 FULL 128-byte lines (8 rows x 128 B) instead of 32 half-lines.  One wave's LDS operations execute in
+// order, so no barrier is needed between its write and its read-back.
+constexpr int TCE_EPI_LDS_FLOATS = 32 * 36;
+
+template <int ACT, int RES>
+__device__ __forceinline__ void tce_epi_store_lds(const f32x16& x, float* __restrict__ wbuf,
+                                                  const float* __restrict__ bias, const float* __restrict__ res,
+                                                  float* __restrict__ C, const int row0, const int col0, const int M,
+                                                  const int N, const long long ldc, const long long ldres,
+                                                  const bool vec_ok, const int lane) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(&wbuf[l31 * 36 + 8 * g + 4 * lhi]) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c4 = (lane & 7) * 4;
+  const int n = col0 + c4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  const bool full = vec_ok && n + 3 < N;
+  if (bias) {
+    if (full) bv = *reinterpret_cast<const f32x4*>(bias + n);
+    else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = (n + c < N) ? bias[n + c] : 0.f;
+    }
+  }
+  f32x4 xv[4], rv[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    xv[it] = *reinterpret_cast<const f32x4*>(&wbuf[r * 36 + c4]);
+    if (RES != 0) {
+      const int row = min(row0 + r, M - 1);
+      if (full) rv[it] = *reinterpret_cast<const f32x4*>(res + (long long)row * ldres + n);
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rv[it][c] = (n + c < N) ? res[(long long)row * ldres + n + c] : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = row0 + it * 8 + (lane >> 3);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = xv[it][c] + bv[c];
+      if (ACT == 1) v = fmaxf(v, 0.f);
+      if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+      if (RES == 1) v += rv[it][c];
+      if (RES == 2) v *= rv[it][c];
+      o[c] = v;
+    }
+    if (row < M) {
+      if (full) *reinterpret_cast<f32x4*>(C + (long long)row * ldc + n) = o;
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (n + c < N) C[(long long)row * ldc + n + c] = o[c];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ bool tce_epi_vec_ok(const float* C, long long ldc, const float* res, long long ldres,
                                                const float* bias, int res_mode) {
   bool ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15u) == 0) && (!bias || ((((uintptr_t)bias) & 15u) == 0));

@@ -254,12 +254,14 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   if (stamps) stamps[2] = (long long)__builtin_amdgcn_s_memtime();
 
   const bool vec_ok = tce_epi_vec_ok(C, p.ldc, res, p.ldres, bias, p.res_mode);
+  // the K loop ended on a workgroup barrier: the stage buffers are free, each wave takes a private slice
+  static_assert(2 * STAGE >= (NT / 64) * TCE_EPI_LDS_FLOATS * 4, "stage LDS too small for the epilogue buffers");
+  float* wbuf = reinterpret_cast<float*>(smem) + wave * TCE_EPI_LDS_FLOATS;
 #define EPI_BODY(ACT, RES)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
-    const int row = tm * BM + wm * WM + i * 32 + l31;                                                       \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                        \
-      tce_epi_store_t<ACT, RES>(acc[i][j], bias, res, C, row, tn * BN + wn * WN + j * 32 + 4 * lhi, p.M,   \
-                                p.N, p.ldc, p.ldres, vec_ok);                                               \
+      tce_epi_store_lds<ACT, RES>(acc[i][j], wbuf, bias, res, C, tm * BM + wm * WM + i * 32,                \
+                                  tn * BN + wn * WN + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane);      \
     }                                                                                                       \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)

@@ -117,6 +117,7 @@ class ReferFormer(nn.Module):
             for p in self.text_encoder.parameters():
                 p.requires_grad_(False)
         self._packed = None
+        self._text = None
         self._arena = None
         self._shape_cache = {}
         self._graphs = {}
@@ -159,6 +160,7 @@ class ReferFormer(nn.Module):
 
     def _invalidate(self):
         self._packed = None
+        self._text = None
         self._shape_cache = {}
         self._graphs = {}
 
@@ -318,8 +320,7 @@ class ReferFormer(nn.Module):
         if self._packed is None:
             self._pack()
         if not self.use_graph:
-            hid, pooled = self._text_eager(ids, att)
-            return self._run(frames, (hid[0].contiguous(), pooled[0].contiguous()), img_h, img_w, None)
+            return self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None)
         # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder beside
         # the pixel decoder
         key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot))
@@ -327,9 +328,8 @@ class ReferFormer(nn.Module):
         if ent is None:
             st = (frames.clone(), ids.clone(), att.clone())
 
-            def text_fn():
-                hid, pooled = self._text_eager(st[1], st[2])
-                return hid[0].contiguous(), pooled[0].contiguous()
+            def text_fn(alloc):
+                return self._text_plan().forward(st[1], alloc)
 
             ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames)
         return self._replay(ent, (frames, ids, att))
@@ -343,7 +343,16 @@ class ReferFormer(nn.Module):
             raise NotImplementedError("padded captions (B > 1) are not supported")
         return ids.to(device), att.to(device)
 
-    def _text_eager(self, ids, att):
+    def _text_plan(self):
+        """RoBERTa on the HIP kernels (text_encoder.py); the HF module only owns the weights."""
+        if self._text is None:
+            from .text_encoder import TextPlan
+            self._text = TextPlan(self.text_encoder)
+        return self._text
+
+    def text_encoder_reference(self, ids, att=None):
+        """HuggingFace's own forward of the same module -- the CHECKER of the HIP text path (tests only)."""
+        att = torch.ones_like(ids) if att is None else att
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
@@ -391,9 +400,11 @@ class ReferFormer(nn.Module):
 
     @torch.no_grad()
     def forward_text_encoder(self, captions, device):
-        """tce_rvos.py:406-424 up to the RoBERTa outputs (third-party arithmetic, runs on PyTorch-ROCm)."""
+        """tce_rvos.py:406-424 up to the RoBERTa outputs: (last_hidden_state [1,L,768], pooler_output [1,768])."""
         ids, att = self._tokenise(captions, device)
-        return self._text_eager(ids, att)
+        hid, pooled = self._text_plan().forward(
+            ids, lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ids.device))
+        return hid[None], pooled[None]
 
     @torch.no_grad()
     def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w):

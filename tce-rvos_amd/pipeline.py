@@ -48,8 +48,8 @@ class _Fork:
 
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None):
-    """text: (last_hidden_state [L,768], pooler_output [768]) or a callable returning them (the RoBERTa forward,
-    run as a parallel branch beside the backbone when a side stream is given).
+    """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
+    forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
     beside the pixel decoder's large kernels; it needs its own arena because both branches allocate."""
     cfg, w = model.cfg, model._packed
@@ -62,7 +62,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     if callable(text):
         text_fork = _Fork(side_stream)
         with text_fork:
-            text = text()
+            text = text((side_arena if side_arena is not None else ar).alloc)
     text_hidden, text_pooled = text
     A = ar.alloc
     sc = model._shape_consts(T, H0, W0, dev)

@@ -1,0 +1,68 @@
+"""RoBERTa forward on the HIP kernels.
+
+The nn.Module that OWNS the weights stays HuggingFace's RobertaModel (so `text_encoder.*` state-dict keys are the
+reference's, tce_rvos.py:137); this file only reads its tensors and replays its arithmetic
+(embeddings -> 12 x [self-attention, output dense + residual + LayerNorm, GELU MLP + residual + LayerNorm] -> pooler)
+with tce_gemm_f32 / tce_layernorm_f32 / tce_embed_ln_f32 / tce_mha_small64_f32 / tce_tanh_f32.
+HF's own forward is used only by the tests, as the checker of this restatement.
+"""
+import torch
+
+from . import ops
+from ._lib import check, lib
+from .ops import ACT_GELU, RES_ADD, gemm_ex
+
+
+class TextPlan:
+    def __init__(self, hf_model):
+        cfg = hf_model.config
+        if cfg.hidden_size % cfg.num_attention_heads or cfg.hidden_size // cfg.num_attention_heads != 64:
+            raise NotImplementedError("text attention kernel is built for head_dim 64 (RoBERTa-base/large)")
+        if getattr(cfg, "hidden_act", "gelu") != "gelu":
+            raise NotImplementedError("only the erf GELU of RoBERTa is implemented")
+        self.C, self.heads, self.ff = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        self.eps = float(cfg.layer_norm_eps)
+        self.pad = int(cfg.pad_token_id)
+        sd = {k: v.detach() for k, v in hf_model.state_dict().items() if v.is_floating_point()}
+        for k, v in sd.items():
+            if not v.is_cuda or v.dtype != torch.float32:
+                raise RuntimeError(f"text_encoder.{k} must be a CUDA float32 tensor")
+        self.sd = sd
+        self.layers = []
+        for i in range(cfg.num_hidden_layers):
+            p = f"encoder.layer.{i}."
+            wqkv = torch.cat([sd[p + "attention.self.query.weight"], sd[p + "attention.self.key.weight"],
+                              sd[p + "attention.self.value.weight"]], 0).contiguous()
+            bqkv = torch.cat([sd[p + "attention.self.query.bias"], sd[p + "attention.self.key.bias"],
+                              sd[p + "attention.self.value.bias"]], 0).contiguous()
+            self.layers.append((wqkv, bqkv, p))
+
+    def forward(self, ids, A):
+        """ids int64 [1, L] on the GPU; A = arena allocator.  Returns (last_hidden_state [L,C], pooler_output [C])."""
+        sd, C, L = self.sd, self.C, ids.shape[1]
+        s = ops._stream()
+        mask = ids.ne(self.pad).to(torch.int64)
+        pos_ids = (torch.cumsum(mask, dim=1) * mask + self.pad).contiguous()  # create_position_ids_from_input_ids
+        x = A(L, C)
+        check(lib().tce_embed_ln_f32(ids.data_ptr(), pos_ids.data_ptr(), sd["embeddings.word_embeddings.weight"].data_ptr(),
+                                     sd["embeddings.position_embeddings.weight"].data_ptr(),
+                                     sd["embeddings.token_type_embeddings.weight"].data_ptr(),
+                                     sd["embeddings.LayerNorm.weight"].data_ptr(), sd["embeddings.LayerNorm.bias"].data_ptr(),
+                                     x.data_ptr(), L, C, self.eps, s), "tce_embed_ln_f32")
+        qkv, att, hdn = A(L, 3 * C), A(L, C), A(L, self.ff)
+        for wqkv, bqkv, p in self.layers:
+            gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv)
+            check(lib().tce_mha_small64_f32(qkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s), "tce_mha_small64_f32")
+            gemm_ex(att, sd[p + "attention.output.dense.weight"], x, L, C, C, C, C, C, bias=sd[p + "attention.output.dense.bias"],
+                    res=x, ldres=C, res_mode=RES_ADD)
+            ops.layernorm(x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], self.eps,
+                          out=x)
+            gemm_ex(x, sd[p + "intermediate.dense.weight"], hdn, L, self.ff, C, C, C, self.ff,
+                    bias=sd[p + "intermediate.dense.bias"], act=ACT_GELU)
+            gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
+                    bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD)
+            ops.layernorm(x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], self.eps, out=x)
+        pooled = A(C)
+        gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])
+        check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), C, s), "tce_tanh_f32")
+        return x, pooled

@@ -173,3 +173,25 @@ def test_flag_combinations_match_oracle(flags):
         for a, b in zip(out["aux_outputs"], ref["aux_outputs"]):
             assert (a["pred_boxes"].cpu() - b["pred_boxes"]).abs().max().item() < 1e-4
             assert (a["pred_masks"].cpu() - b["pred_masks"]).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("layers,L", [(1, 7), (12, 32), (2, 100)])
+def test_text_encoder_hip_matches_huggingface(layers, L):
+    """RoBERTa on the HIP kernels vs HuggingFace's own forward of the same module (same weights, same ids)."""
+    import transformers
+    from tce_rvos_amd.text_encoder import TextPlan
+    torch.manual_seed(layers)
+    hf = transformers.RobertaModel(transformers.RobertaConfig(
+        vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, num_hidden_layers=layers)).cuda().eval()
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(3, 50264, (1, L), generator=g)
+    ids[0, 0], ids[0, -1] = 0, 2
+    ids = ids.cuda()
+    with torch.no_grad():
+        enc = hf(input_ids=ids, attention_mask=torch.ones_like(ids))
+        hid, pooled = TextPlan(hf).forward(ids, lambda *s: torch.empty(*s, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    d1 = (hid - enc.last_hidden_state[0]).abs().max().item()
+    d2 = (pooled - enc.pooler_output[0]).abs().max().item()
+    print("text encoder max abs diff: hidden", d1, "pooled", d2)
+    assert d1 < 2e-4 and d2 < 1e-4
