@@ -58,6 +58,7 @@ int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int3
 int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
 /* diagnostic: register (or clear with NULL) a device buffer of >= 2048*8 int64 for in-kernel s_memtime stamps */
 int tce_debug_set_stamp_buffer(long long* dev_buf);
+int tce_debug_set_epilogue(int32_t lds_staged); /* tuning aid: 1 (default) LDS-staged coalesced stores, 0 direct */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 

@@ -62,6 +62,7 @@ __device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo
 // workgroups of the symmetric kernel records s_memtime at entry / after the prologue / after the K loop / after
 // the epilogue stores were issued / after they drained.  NULL (the default) costs one uniform branch.
 __device__ long long* g_stamp_buf = nullptr;
+__device__ int g_epi_lds = 1;  // tuning aid: 1 = LDS-staged coalesced epilogue, 0 = direct row-per-lane stores
 
 // Symmetric kernel: every wave loads, converts and multiplies.  DEPTH K-slices are kept in flight per thread in a
 // register ring (loads are unconditional -- clamped addresses, validity applied at commit -- and the steady-state
@@ -257,11 +258,18 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   // the K loop ended on a workgroup barrier: the stage buffers are free, each wave takes a private slice
   static_assert(2 * STAGE >= (NT / 64) * TCE_EPI_LDS_FLOATS * 4, "stage LDS too small for the epilogue buffers");
   float* wbuf = reinterpret_cast<float*>(smem) + wave * TCE_EPI_LDS_FLOATS;
+  // measured (tools/gemm_stamps.py): LDS staging pays for the 8-wave 256x128 tile (9.1k -> 7.7k cycles), not for the
+  // 4-wave tiles (3.6k -> 5.0k), where direct row-per-lane float4 stores stay
+  const bool epi_lds = (WAVES_M == 4) && g_epi_lds != 0;
 #define EPI_BODY(ACT, RES)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                        \
-      tce_epi_store_lds<ACT, RES>(acc[i][j], wbuf, bias, res, C, tm * BM + wm * WM + i * 32,                \
-                                  tn * BN + wn * WN + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane);      \
+      if (epi_lds)                                                                                          \
+        tce_epi_store_lds<ACT, RES>(acc[i][j], wbuf, bias, res, C, tm * BM + wm * WM + i * 32,              \
+                                    tn * BN + wn * WN + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane);    \
+      else                                                                                                  \
+        tce_epi_store_t<ACT, RES>(acc[i][j], bias, res, C, tm * BM + wm * WM + i * 32 + l31,                \
+                                  tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N, p.ldc, p.ldres, vec_ok);  \
     }                                                                                                       \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
@@ -562,6 +570,15 @@ bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL((gemm_f16x3_pc_kernel<false, false>), dim3(G), dim3(512), 0, s, a, tiles_m, tiles_n, (int)total, g_pc_ablate);
   return true;
+}
+
+extern "C" int tce_debug_set_epilogue(int32_t lds_staged) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_epi_lds), &lds_staged, sizeof(lds_staged));
+  if (e != hipSuccess) {
+    tce_set_error("tce_debug_set_epilogue: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  return TCE_OK;
 }
 
 extern "C" int tce_debug_set_stamp_buffer(long long* dev_buf) {

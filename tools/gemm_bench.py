@@ -44,6 +44,8 @@ def bench(fn, iters=10, graph=False):
 def main():
     modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f32", "f16x3"]
     tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+    if len(sys.argv) > 3:
+        lib().tce_debug_set_epilogue(int(sys.argv[3]))
     tot = {}
     for (M, N, K, cnt, tag) in SHAPES:
         a = torch.randn(M, K, device="cuda")
