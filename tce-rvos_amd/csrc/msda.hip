@@ -123,15 +123,6 @@ __global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ val
   if (active) out[item * D + d] = acc;
 }
 
-__global__ void read_levels_kernel(const int64_t* shapes, const int64_t* starts, int L, int* out) {
-  const int i = threadIdx.x;
-  if (i < L) {
-    out[i] = (int)shapes[2 * i];
-    out[MAXL + i] = (int)shapes[2 * i + 1];
-    out[2 * MAXL + i] = (int)starts[i];
-  }
-}
-
 // variant of the plain kernel that reads level geometry from device memory (the reference op passes
 // spatial_shapes / level_start_index as device int64 tensors)
 __global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __restrict__ value,
