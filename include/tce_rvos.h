@@ -62,6 +62,15 @@ int tce_debug_set_epilogue(int32_t lds_staged); /* tuning aid: 1 (default) LDS-s
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 
+/* PROTOTYPE of the next GEMM generation: operands pre-split into fp16 planes in HBM
+ * (tce_split_f16_f32: hi = f16_rtz(x (+add)), lo = f16_rtz(x - hi)), K slices staged HBM -> LDS by DMA into a 3-stage
+ * ring; same arithmetic and epilogue as tce_gemm_f32's split mode.  A/W planes [rows, K] fp16, pitches in halfs. */
+int tce_split_f16_f32(const float* x, const float* add, void* hi, void* lo, int64_t rows, int32_t cols,
+                      int64_t add_rows, tceStream stream);
+int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias, const float* res,
+                    float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres,
+                    int32_t act, int32_t res_mode, tceStream stream);
+
 /* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
  * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */
 int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, float* out,

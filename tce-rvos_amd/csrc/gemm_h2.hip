@@ -1,0 +1,203 @@
+// PROTOTYPE (tools/gemm_h2_bench.py; not on the product path): the split-fp16 GEMM with PRE-SPLIT operands and LDS-DMA
+// staging.  Measured (MI355X): correct to the same error as the shipped kernel but only 0-10 % faster, and with the
+// MFMAs removed it still needs ~80 % of its time -- the K loop of these fp32-activation GEMMs is bound by the
+// operand feed (64-128 B pieces of many rows per slice), not by VALU conversion, LDS or the matrix pipe; the lever is
+// a K-panel-blocked activation layout / fewer bytes, not the staging mechanism.
+//
+// Operands arrive as fp16 planes (hi, lo) in HBM -- produced by tce_split_f16_f32 here; in the planned dataflow
+// by the epilogue of whichever kernel produced the tensor -- so a K slice moves HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no conversion VALU, no ds_write) into a 3-stage ring, two slices ahead
+// of the MFMAs, behind counted s_waitcnt vmcnt(N) and one raw s_barrier per slice.  The LDS image is lane-linear
+// per DMA instruction (16 rows x 64 B), so the bank-conflict-free XOR swizzle is applied on the SOURCE address.
+// 256x128 tile, 8 waves (4x2) of 64x64, BK = 32, 48 KiB per stage.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
+constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;  // 49152
+constexpr int NSTAGE = 3;
+constexpr int DMA_PER_WAVE = (STAGE / 1024) / 8;  // 6
+
+__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+struct H2Args {
+  const _Float16 *Ah, *Al, *Wh, *Wl;
+  const float *bias, *res;
+  float* C;
+  int M, N, K, lda, ldw, ldc, ldres, act, res_mode;
+};
+
+__global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const int tiles_m, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];  // the ONLY LDS object: base offset 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int nk = p.K / BK;
+
+  // this wave's 6 DMA instructions per stage: instruction id -> (plane, first row); lane -> (row, 16-byte slot)
+  const _Float16* src[DMA_PER_WAVE];
+  unsigned dst[DMA_PER_WAVE];
+#pragma unroll
+  for (int q = 0; q < DMA_PER_WAVE; ++q) {
+    const int id = wave + 8 * q;  // 0..47
+    const _Float16* base;
+    int row0, ld, grow0, lim, off;
+    if (id < 16) { base = p.Ah; row0 = id * 16; ld = p.lda; grow0 = tm * BM; lim = p.M; off = 0; }
+    else if (id < 32) { base = p.Al; row0 = (id - 16) * 16; ld = p.lda; grow0 = tm * BM; lim = p.M; off = PLANE_A; }
+    else if (id < 40) { base = p.Wh; row0 = (id - 32) * 16; ld = p.ldw; grow0 = tn * BN; lim = p.N; off = 2 * PLANE_A; }
+    else { base = p.Wl; row0 = (id - 40) * 16; ld = p.ldw; grow0 = tn * BN; lim = p.N; off = 2 * PLANE_A + PLANE_B; }
+    const int row = row0 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);          // inverse swizzle on the source
+    const int grow = min(grow0 + row, lim - 1);            // rows past the edge only feed outputs never stored
+    src[q] = base + (long long)grow * ld + c * 8;
+    dst[q] = (unsigned)(off + row0 * 64);
+  }
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q)
+      glds16(src[q] + (long long)kt * BK, __builtin_amdgcn_readfirstlane(dst[q] + (unsigned)(slot * STAGE)));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // Fragment registers are double-buffered across K slices: the ds_reads of slice kt+1 (first k16 half) are issued
+  // at the end of slice kt, so after the barrier the matrix pipe restarts from registers instead of waiting an LDS
+  // round trip; the second half's reads are issued at the top and land under the first half's MFMAs.
+  h16x8 fa[2][2][2], fb[2][2][2];  // [k16 half][tile][hi/lo]
+  auto read_half = [&](const unsigned char* st, int ks) {
+    const int c = ks * 2 + lhi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = swz(wm * 64 + i * 32 + l31, c);
+      fa[ks][i][0] = *reinterpret_cast<const h16x8*>(st + off);
+      fa[ks][i][1] = *reinterpret_cast<const h16x8*>(st + PLANE_A + off);
+      const int offb = swz(wn * 64 + i * 32 + l31, c);
+      fb[ks][i][0] = *reinterpret_cast<const h16x8*>(st + 2 * PLANE_A + offb);
+      fb[ks][i][1] = *reinterpret_cast<const h16x8*>(st + 2 * PLANE_A + PLANE_B + offb);
+    }
+  };
+  auto mfma_half = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][1], fa[ks][i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][0], fa[ks][i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][0], fa[ks][i][0], acc[i][j], 0, 0, 0);
+      }
+  };
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  // publish slice 0 and preload its first half
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_half(smem, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt % NSTAGE) * STAGE;
+    read_half(st, 1);
+    // slice kt+1 (issued one slice ago) must be complete and visible before its fragments are prefetched below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);  // its slot held slice kt-1: every wave is past those reads
+    mfma_half(0);
+    if (kt + 1 < nk) read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 0);  // lands under the second half's MFMAs
+    mfma_half(1);
+  }
+  __syncthreads();  // every wave is done reading the ring before it becomes epilogue scratch
+  const bool vec_ok = tce_epi_vec_ok(p.C, p.ldc, p.res, p.ldres, p.bias, p.res_mode);
+  float* wbuf = reinterpret_cast<float*>(smem) + wave * TCE_EPI_LDS_FLOATS;
+#define EPI_BODY(ACT, RES)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+        tce_epi_store_lds<ACT, RES>(acc[i][j], wbuf, p.bias, p.res, p.C, tm * BM + wm * 64 + i * 32,           \
+                                    tn * BN + wn * 64 + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane);       \
+  }
+  TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
+#undef EPI_BODY
+}
+
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+struct h4pair {
+  fp16x2_t a, b;
+};
+
+// x (+ add) -> fp16 planes hi = f16_rtz(x), lo = f16_rtz(x - hi); `add` has period add_rows rows (shared position map)
+__global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                        _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                        long long n4, int C4, long long add_rows) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  if (add) {
+    const long long row = i / C4;
+    v += reinterpret_cast<const f32x4*>(add)[(row % add_rows) * C4 + (i - row * C4)];
+  }
+  h4pair h, l;
+  h.a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+  h.b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+  l.a = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h.a[0], v[1] - (float)h.a[1]);
+  l.b = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h.b[0], v[3] - (float)h.b[1]);
+  reinterpret_cast<h4pair*>(hi)[i] = h;
+  reinterpret_cast<h4pair*>(lo)[i] = l;
+}
+
+}  // namespace
+
+extern "C" int tce_split_f16_f32(const float* x, const float* add, void* hi, void* lo, int64_t rows, int32_t cols,
+                                 int64_t add_rows, tceStream stream) {
+  TCE_CHECK_ARG(x && hi && lo && rows > 0 && cols > 0 && cols % 4 == 0, "tce_split_f16_f32: bad arguments");
+  const long long n4 = (long long)rows * (cols / 4);
+  hipLaunchKernelGGL(split_f16_kernel, dim3(tce_cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, add,
+                     (_Float16*)hi, (_Float16*)lo, n4, cols / 4, (long long)(add_rows > 0 ? add_rows : rows));
+  TCE_CHECK_LAUNCH("tce_split_f16_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
+                               const float* res, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                               int32_t ldc, int32_t ldres, int32_t act, int32_t res_mode, tceStream stream) {
+  TCE_CHECK_ARG(Ah && Al && Wh && Wl && C, "tce_gemm_h2_f32: null pointer");
+  TCE_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "tce_gemm_h2_f32: K=%d must be a positive multiple of %d", K, BK);
+  TCE_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && tce_aligned16(Ah) && tce_aligned16(Al) && tce_aligned16(Wh) &&
+                    tce_aligned16(Wl),
+                "tce_gemm_h2_f32: planes must be 16-byte aligned with pitches multiple of 8 halfs");
+  H2Args a;
+  a.Ah = (const _Float16*)Ah; a.Al = (const _Float16*)Al; a.Wh = (const _Float16*)Wh; a.Wl = (const _Float16*)Wl;
+  a.bias = bias; a.res = res; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldres = ldres; a.act = act; a.res_mode = res_mode;
+  const int tiles_m = tce_cdiv(M, BM), tiles_n = tce_cdiv(N, BN);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_h2_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, a, tiles_m, tiles_n);
+  TCE_CHECK_LAUNCH("tce_gemm_h2_f32");
+  return TCE_OK;
+}

@@ -372,3 +372,26 @@ def test_harness_select_masks_matches_reference_caller(ops):
         assert int(best.item()) == int(fx[f"h{i}_best"])
         ref = torch.from_numpy(fx[f"h{i}_out"])
         assert O.mask_iou(m.cpu().bool(), ref) > 1 - 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 384, 96), (2049, 130, 256)])
+def test_gemm_presplit_dma_prototype(ops, M, N, K):
+    """tce_split_f16_f32 + tce_gemm_h2_f32 (pre-split operands, LDS-DMA ring): same arithmetic as the shipped split GEMM."""
+    from tce_rvos_amd._lib import lib, check
+    g = torch.Generator().manual_seed(M)
+    a, pos = torch.randn(M, K, generator=g), torch.randn(100, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    da, dpos, dw, db = dev(a), dev(pos), dev(w), dev(b)
+    planes = [torch.empty(M, K, dtype=torch.float16, device="cuda") for _ in range(2)] + \
+             [torch.empty(N, K, dtype=torch.float16, device="cuda") for _ in range(2)]
+    check(lib().tce_split_f16_f32(da.data_ptr(), dpos.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), M, K, 100,
+                                  ops._stream()), "split A")
+    check(lib().tce_split_f16_f32(dw.data_ptr(), None, planes[2].data_ptr(), planes[3].data_ptr(), N, K, 0, ops._stream()),
+          "split W")
+    a_eff = a + pos[torch.arange(M) % 100]
+    rec = planes[0].float().cpu() + planes[1].float().cpu()
+    assert (rec - a_eff).abs().max().item() < 2e-6 * a_eff.abs().max().item() + 1e-7
+    out = torch.empty(M, N, device="cuda")
+    check(lib().tce_gemm_h2_f32(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(),
+                                db.data_ptr(), None, out.data_ptr(), M, N, K, K, K, N, 0, 2, 0, ops._stream()), "h2")
+    close(out, F.gelu(F.linear(a_eff, w, b)), 1e-4, 1e-4)
