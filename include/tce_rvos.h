@@ -58,6 +58,8 @@ int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int3
 int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
 /* diagnostic: register (or clear with NULL) a device buffer of >= 2048*8 int64 for in-kernel s_memtime stamps */
 int tce_debug_set_stamp_buffer(long long* dev_buf);
+/* same for the prototype GEMM (tce_gemm_h2_f32): >= 256*8*8 int64, per-wave phase sums */
+int tce_debug_h2_set_stamp_buffer(long long* dev_buf);
 int tce_debug_set_epilogue(int32_t lds_staged); /* tuning aid: 1 (default) LDS-staged coalesced stores, 0 direct */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
@@ -69,7 +71,8 @@ int tce_split_f16_f32(const float* x, const float* add, void* hi, void* lo, int6
                       int64_t add_rows, tceStream stream);
 int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias, const float* res,
                     float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres,
-                    int32_t act, int32_t res_mode, tceStream stream);
+                    int32_t act, int32_t res_mode, int64_t a_slice /* 0/32: row-major A; M*32 with lda=32: K-slice-major A [K/32][M][32] */,
+                    tceStream stream);
 
 /* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
  * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */

@@ -32,11 +32,12 @@ SIGNATURES = {
     "tce_gemm_select_tile_ex": (i32, [i32, i32, i32, i32, i32]),
     "tce_gemm_force_tile": (i32, [i32]),
     "tce_debug_set_stamp_buffer": (i32, [c_f]),
+    "tce_debug_h2_set_stamp_buffer": (i32, [c_f]),
     "tce_debug_set_epilogue": (i32, [i32]),
     "tce_set_gemm_mode": (i32, [i32]),
     "tce_get_gemm_mode": (i32, []),
     "tce_split_f16_f32": (i32, [c_f, c_f, c_f, c_f, i64, i32, i64, c_f]),
-    "tce_gemm_h2_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_gemm_h2_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, c_f]),
     "tce_layernorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, c_f]),
     "tce_groupnorm_nsplit": (i32, [i32]),
     "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),

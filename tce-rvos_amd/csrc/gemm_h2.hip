@@ -34,11 +34,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// Diagnostic (tce_debug_h2_set_stamp_buffer): per wave of the first 256 workgroups, summed s_memtime ticks spent in
+// [0] the counted vmcnt wait, [1] the barrier, [2] DMA issue, [3] fragment reads + MFMAs, [4] whole K loop.
+__device__ long long* g_h2_stamps = nullptr;
+
 struct H2Args {
   const _Float16 *Ah, *Al, *Wh, *Wl;
   const float *bias, *res;
   float* C;
   int M, N, K, lda, ldw, ldc, ldres, act, res_mode;
+  long long a_slice;  // elements between consecutive 32-wide K slices of A (row-major: 32; slice-major [K/32][M][32]: M*32)
 };
 
 __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const int tiles_m, const int tiles_n) {
@@ -70,8 +75,11 @@ __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const i
   }
   auto issue = [&](int kt, int slot) {
 #pragma unroll
-    for (int q = 0; q < DMA_PER_WAVE; ++q)
-      glds16(src[q] + (long long)kt * BK, __builtin_amdgcn_readfirstlane(dst[q] + (unsigned)(slot * STAGE)));
+    for (int q = 0; q < DMA_PER_WAVE; ++q) {
+      const bool is_a = (wave + 8 * q) < 32;
+      glds16(src[q] + (long long)kt * (is_a ? p.a_slice : (long long)BK),
+             __builtin_amdgcn_readfirstlane(dst[q] + (unsigned)(slot * STAGE)));
+    }
   };
 
   f32x16 acc[2][2];
@@ -109,25 +117,39 @@ __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const i
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][0], fa[ks][i][0], acc[i][j], 0, 0, 0);
       }
   };
+  // Ring discipline: at the top of slice kt this wave's DMAs of slice kt have landed (counted vmcnt leaves the 6
+  // of slice kt+1 in flight), the barrier publishes every wave's share and proves slot (kt+2)%3 -- slice kt-1 --
+  // is no longer read, so slice kt+2 is issued right behind it: two full slices (96 KiB per CU) stay in flight.
+  long long* const stamps = (g_h2_stamps && blockIdx.x < 256) ? g_h2_stamps + (blockIdx.x * 8 + wave) * 8 : nullptr;
+  long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_begin = 0;
+  if (stamps) t_begin = (long long)__builtin_amdgcn_s_memtime();
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  // publish slice 0 and preload its first half
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  read_half(smem, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt % NSTAGE) * STAGE;
-    read_half(st, 1);
-    // slice kt+1 (issued one slice ago) must be complete and visible before its fragments are prefetched below
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (stamps) t0 = (long long)__builtin_amdgcn_s_memtime();
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamps) t1 = (long long)__builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);  // its slot held slice kt-1: every wave is past those reads
+    if (stamps) t2 = (long long)__builtin_amdgcn_s_memtime();
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
+    if (stamps) t3 = (long long)__builtin_amdgcn_s_memtime();
+    read_half(st, 0);
+    read_half(st, 1);
     mfma_half(0);
-    if (kt + 1 < nk) read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 0);  // lands under the second half's MFMAs
     mfma_half(1);
+    if (stamps) {
+      __builtin_amdgcn_sched_barrier(0);
+      const long long t4 = (long long)__builtin_amdgcn_s_memtime();
+      t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2; t_comp += t4 - t3;
+    }
+  }
+  if (stamps && lane == 0) {
+    stamps[0] = t_wait; stamps[1] = t_bar; stamps[2] = t_issue; stamps[3] = t_comp;
+    stamps[4] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
   }
   __syncthreads();  // every wave is done reading the ring before it becomes epilogue scratch
   const bool vec_ok = tce_epi_vec_ok(p.C, p.ldc, p.res, p.ldres, p.bias, p.res_mode);
@@ -169,6 +191,15 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int tce_debug_h2_set_stamp_buffer(long long* dev_buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_h2_stamps), &dev_buf, sizeof(dev_buf));
+  if (e != hipSuccess) {
+    tce_set_error("tce_debug_h2_set_stamp_buffer: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  return TCE_OK;
+}
+
 extern "C" int tce_split_f16_f32(const float* x, const float* add, void* hi, void* lo, int64_t rows, int32_t cols,
                                  int64_t add_rows, tceStream stream) {
   TCE_CHECK_ARG(x && hi && lo && rows > 0 && cols > 0 && cols % 4 == 0, "tce_split_f16_f32: bad arguments");
@@ -181,7 +212,8 @@ extern "C" int tce_split_f16_f32(const float* x, const float* add, void* hi, voi
 
 extern "C" int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
                                const float* res, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
-                               int32_t ldc, int32_t ldres, int32_t act, int32_t res_mode, tceStream stream) {
+                               int32_t ldc, int32_t ldres, int32_t act, int32_t res_mode, int64_t a_slice,
+                               tceStream stream) {
   TCE_CHECK_ARG(Ah && Al && Wh && Wl && C, "tce_gemm_h2_f32: null pointer");
   TCE_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "tce_gemm_h2_f32: K=%d must be a positive multiple of %d", K, BK);
   TCE_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && tce_aligned16(Ah) && tce_aligned16(Al) && tce_aligned16(Wh) &&
@@ -191,6 +223,7 @@ extern "C" int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, c
   a.Ah = (const _Float16*)Ah; a.Al = (const _Float16*)Al; a.Wh = (const _Float16*)Wh; a.Wl = (const _Float16*)Wl;
   a.bias = bias; a.res = res; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldres = ldres; a.act = act; a.res_mode = res_mode;
+  a.a_slice = a_slice > 0 ? a_slice : BK;
   const int tiles_m = tce_cdiv(M, BM), tiles_n = tce_cdiv(N, BN);
   static bool attr = false;
   if (!attr) {

@@ -393,5 +393,5 @@ def test_gemm_presplit_dma_prototype(ops, M, N, K):
     assert (rec - a_eff).abs().max().item() < 2e-6 * a_eff.abs().max().item() + 1e-7
     out = torch.empty(M, N, device="cuda")
     check(lib().tce_gemm_h2_f32(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(),
-                                db.data_ptr(), None, out.data_ptr(), M, N, K, K, K, N, 0, 2, 0, ops._stream()), "h2")
+                                db.data_ptr(), None, out.data_ptr(), M, N, K, K, K, N, 0, 2, 0, 0, ops._stream()), "h2")
     close(out, F.gelu(F.linear(a_eff, w, b)), 1e-4, 1e-4)
