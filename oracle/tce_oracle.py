@@ -67,7 +67,13 @@ class OracleConfig:
         return "video_swin" in self.backbone
 
     @property
+    def is_resnet(self):
+        return self.backbone.startswith("resnet")
+
+    @property
     def num_channels(self):
+        if self.is_resnet:  # backbone.py:68
+            return [256, 512, 1024, 2048]
         return [self.embed_dim * 2 ** i for i in range(len(self.depths))]
 
 
@@ -353,6 +359,43 @@ def swin_backbone(sd, cfg: OracleConfig, frames: Tensor, pre="backbone.0.body.")
         if i < len(cfg.depths) - 1:
             x = patch_merging(sd, f"{pre}layers.{i}.downsample.", x, H, W)
             H, W = (H + 1) // 2, (W + 1) // 2
+    return outs
+
+
+# --------------------------------------------------------------------------------------
+# ResNet-50 backbone (models/backbone.py; body = torchvision resnet50, absent from /root/reference and from this image:
+# restated from its published definition -- He et al. 2016 bottleneck, "v1.5" stride on the 3x3 -- and anchored on the
+# reference's call site backbone.py:92-96 and its own FrozenBatchNorm2d :20-56, IntermediateLayerGetter names :64-74)
+# --------------------------------------------------------------------------------------
+def frozen_bn(sd, pre, x: Tensor) -> Tensor:
+    """backbone.py:46-56: scale = w * rsqrt(var + 1e-5); bias = b - mean * scale; x * scale + bias."""
+    scale = sd[pre + "weight"] * (sd[pre + "running_var"] + 1e-5).rsqrt()
+    bias = sd[pre + "bias"] - sd[pre + "running_mean"] * scale
+    return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def resnet_bottleneck(sd, pre, x: Tensor, stride: int) -> Tensor:
+    idt = x
+    if pre + "downsample.0.weight" in sd:
+        idt = frozen_bn(sd, pre + "downsample.1.", F.conv2d(x, sd[pre + "downsample.0.weight"], stride=stride))
+    y = F.relu(frozen_bn(sd, pre + "bn1.", F.conv2d(x, sd[pre + "conv1.weight"])))
+    y = F.relu(frozen_bn(sd, pre + "bn2.", F.conv2d(y, sd[pre + "conv2.weight"], stride=stride, padding=1)))
+    y = frozen_bn(sd, pre + "bn3.", F.conv2d(y, sd[pre + "conv3.weight"]))
+    return F.relu(y + idt)
+
+
+RESNET50_BLOCKS = (3, 4, 6, 3)
+
+
+def resnet_backbone(sd, cfg: OracleConfig, frames: Tensor, pre="backbone.0.body.") -> List[Tensor]:
+    """frames [T,3,H,W] -> layer1..layer4 maps (backbone.py:64-74: strides 4, 8, 16, 32)."""
+    x = F.relu(frozen_bn(sd, pre + "bn1.", F.conv2d(frames, sd[pre + "conv1.weight"], stride=2, padding=3)))
+    x = F.max_pool2d(x, 3, stride=2, padding=1)
+    outs = []
+    for li, blocks in enumerate(RESNET50_BLOCKS):
+        for b in range(blocks):
+            x = resnet_bottleneck(sd, f"{pre}layer{li + 1}.{b}.", x, 2 if (b == 0 and li > 0) else 1)
+        outs.append(x)
     return outs
 
 
@@ -813,7 +856,9 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidde
     stages = {}
 
     # backbone + per-level masks + sine pos  (Joiner, swin_transformer.py:665-677,632-640)
-    if cfg.is_video_swin:
+    if cfg.is_resnet:
+        feats = resnet_backbone(sd, cfg, frames)
+    elif cfg.is_video_swin:
         feats = video_swin_backbone(sd, cfg, frames[None])
     else:
         feats = swin_backbone(sd, cfg, frames)

@@ -19,6 +19,9 @@ _NORM_W = re.compile(r"(^|\.)(norm\d*|layer_norm|norm)\.weight$|input_proj\.\d+\
 _NORM_B = re.compile(r"(^|\.)(norm\d*|layer_norm|norm)\.bias$|input_proj\.\d+\.1\.bias$")
 
 
+_FBN = re.compile(r"^backbone\.0\.body\..*(bn\d|downsample\.1)\.(weight|bias|running_mean|running_var)$")
+
+
 def _gen(key: str, salt: int) -> torch.Generator:
     return torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ (salt * 0x9E3779B1)) & 0x7FFFFFFF)
 
@@ -29,6 +32,12 @@ def synth_tensor(key: str, shape, salt: int = 0) -> torch.Tensor:
     key = key.replace("transformer.decoder.bbox_embed.", "bbox_embed.")
     g = _gen(key, salt)
     r = torch.randn(shape, generator=g, dtype=torch.float32)
+    if _FBN.search(key):  # FrozenBatchNorm2d buffers of the ResNet backbone (backbone.py:20-56)
+        if key.endswith("running_var"):
+            return 0.6 + 0.8 * torch.rand(shape, generator=g, dtype=torch.float32)
+        if key.endswith("running_mean"):
+            return 0.1 * r
+        return 1.0 + 0.1 * r if key.endswith("weight") else 0.05 * r
     if _NORM_W.search(key):
         return 1.0 + 0.1 * r
     if _NORM_B.search(key):

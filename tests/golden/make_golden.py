@@ -183,7 +183,19 @@ def gen_harness():
     np.savez_compressed(os.path.join(HERE, "harness_cases.npz"), **out)
 
 
+def gen_resnet():
+    """BASELINE config 1 (ResNet-50, T=1): a small clip with stages + the full 360x640 frame (outputs only)."""
+    m = gen_e2e("e2e_resnet50_small.npz", "resnet50", T=2, H=72, W=100, seed=6,
+                stage_keys=("backbone0", "backbone3", "memory"))
+    gen_statedict_manifest(m, "statedict_resnet50.json")
+    gen_e2e("e2e_resnet50_cfg1.npz", "resnet50", T=1, H=360, W=640, seed=8, store_stages=False)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet":
+        torch.set_num_threads(8)
+        gen_resnet()
+        sys.exit(0)
     torch.set_num_threads(8)
     gen_msda()
     gen_interp()
@@ -196,4 +208,5 @@ if __name__ == "__main__":
     # BASELINE config 2 at full size: only the outputs are kept (inputs/weights regenerate from seeds)
     gen_e2e("e2e_swin_t_cfg2.npz", "swin_t_p4w7", T=5, H=360, W=640, seed=4, store_stages=False)
     gen_plain_manifest()
+    gen_resnet()
     print("done")

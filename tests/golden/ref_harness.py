@@ -33,11 +33,76 @@ def _install_standins():
         tv_models_utils = types.ModuleType("torchvision.models._utils")
 
         class IntermediateLayerGetter(nn.ModuleDict):
+            """torchvision is absent: the children of `model` up to the last requested one, run in order, the
+            requested outputs collected under their new names (what backbone.py:74,77 relies on)."""
+
             def __init__(self, model, return_layers):
-                super().__init__()
-                raise RuntimeError("ResNet backbone is not available in this container")
+                todo = dict(return_layers)
+                kept = {}
+                for name, child in model.named_children():
+                    kept[name] = child
+                    todo.pop(name, None)
+                    if not todo:
+                        break
+                super().__init__(kept)
+                self.return_layers = dict(return_layers)
+
+            def forward(self, x):
+                out = {}
+                for name, child in self.items():
+                    x = child(x)
+                    if name in self.return_layers:
+                        out[self.return_layers[name]] = x
+                return out
 
         tv_models_utils.IntermediateLayerGetter = IntermediateLayerGetter
+
+        class _Bottleneck(nn.Module):
+            # ResNet "v1.5" bottleneck as published (He et al. 2016; torchvision places the stride on the 3x3)
+            def __init__(self, cin, width, stride, norm_layer, project):
+                super().__init__()
+                self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+                self.bn1 = norm_layer(width)
+                self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+                self.bn2 = norm_layer(width)
+                self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+                self.bn3 = norm_layer(width * 4)
+                self.relu = nn.ReLU(inplace=True)
+                self.downsample = None
+                if project:
+                    self.downsample = nn.Sequential(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False),
+                                                    norm_layer(width * 4))
+
+            def forward(self, x):
+                idt = x if self.downsample is None else self.downsample(x)
+                y = self.relu(self.bn1(self.conv1(x)))
+                y = self.relu(self.bn2(self.conv2(y)))
+                y = self.bn3(self.conv3(y))
+                return self.relu(y + idt)
+
+        class _ResNet50(nn.Module):
+            def __init__(self, norm_layer):
+                super().__init__()
+                self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+                self.bn1 = norm_layer(64)
+                self.relu = nn.ReLU(inplace=True)
+                self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+                cin = 64
+                for li, (width, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+                    layer = []
+                    for b in range(blocks):
+                        layer.append(_Bottleneck(cin, width, stride if b == 0 else 1, norm_layer, b == 0))
+                        cin = width * 4
+                    setattr(self, f"layer{li + 1}", nn.Sequential(*layer))
+                self.avgpool = nn.AdaptiveAvgPool2d(1)
+                self.fc = nn.Linear(2048, 1000)
+
+        def resnet50(replace_stride_with_dilation=None, pretrained=False, norm_layer=None, **kw):
+            # `pretrained` would download weights (backbone.py:94-96): never honoured here, weights are synthetic
+            assert not any(replace_stride_with_dilation or ()), "dilation is not part of any BASELINE config"
+            return _ResNet50(norm_layer or nn.BatchNorm2d)
+
+        tv_models.resnet50 = resnet50
         tv_ops = types.ModuleType("torchvision.ops")
         tv_ops.__path__ = []
         tv_ops_misc = types.ModuleType("torchvision.ops.misc")

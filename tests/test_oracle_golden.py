@@ -86,6 +86,22 @@ def test_e2e_video_swin_t_small_matches_reference():
         assert torch.allclose(st["backbone"][i], torch.from_numpy(fx[f"stage_backbone{i}"]), rtol=1e-4, atol=1e-4), i
 
 
+def test_e2e_resnet50_small_matches_reference():
+    """Row A11: reference FrozenBatchNorm2d / BackboneBase / Joiner over the restated ResNet-50 body."""
+    fx, out = _run_e2e("e2e_resnet50_small.npz", "statedict_resnet50.json", "resnet50")
+    _check_outputs(fx, out, 2e-3)
+    st = out["_stages"]
+    for i in (0, 3):
+        assert torch.allclose(st["backbone"][i], torch.from_numpy(fx[f"stage_backbone{i}"]), rtol=1e-4, atol=1e-4), i
+
+
+@pytest.mark.slow
+def test_e2e_resnet50_config1_fullsize_matches_reference():
+    """BASELINE config 1 (ResNet-50, T=1, 360x640)."""
+    fx, out = _run_e2e("e2e_resnet50_cfg1.npz", "statedict_resnet50.json", "resnet50")
+    _check_outputs(fx, out, 5e-3)
+
+
 @pytest.mark.slow
 def test_e2e_swin_t_config2_fullsize_matches_reference():
     """BASELINE config 2 (T=5, 360x640) -- ~15 s of CPU."""
