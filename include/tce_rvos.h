@@ -26,7 +26,8 @@ const char* tce_last_error(void);
 /* ---------------------------------------------------------------------------------------------------
  * Dense contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
  *   C[M,N] = epi( (A[M,K] (+ A2[M,K])) @ W[N,K]^T + bias[N] )
- *   epi:  act 0 none | 1 ReLU | 2 GELU(erf);  then res_mode 0 none | 1 "+ res[M,N]" | 2 "* res[M,N]".
+ *   epi:  act 0 none | 1 ReLU | 2 GELU(erf);  then res_mode 0 none | 1 "+ res[M,N]" | 2 "* res[M,N]";
+ *         act 3 = ReLU applied AFTER the residual (ResNet bottleneck: relu(bn(conv) + identity)).
  * Replaces every nn.Linear / 1x1 Conv2d on the path, and (conv != 0) nn.Conv2d kxk as implicit GEMM over a
  * channels-last image A[T,H,Wd,Cin] with W[N, kh*kw*Cin] (k = (ky*kw+kx)*Cin + c), M = T*Ho*Wo.
  * batch > 1 runs `batch` independent problems (grid.z) with element strides sA.. (0 = shared).
@@ -85,6 +86,14 @@ int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const 
 int tce_groupnorm_nsplit(int32_t HW);
 int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
                       int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream);
+
+/* ResNet-50 stem (row A11; models/backbone.py:92-96 builds torchvision's resnet50 with FrozenBatchNorm2d :46-56):
+ * conv 7x7 stride 2 pad 3, 3 -> 64, + folded frozen BN + ReLU.  frames NCHW [T,3,H,W] -> channels-last
+ * [T*Ho*Wo, 64], Ho = (H-1)/2+1.  w_k64 [147][64] with k = (c*7+ky)*7+kx and the BN scale folded in; bias[64]. */
+int tce_resnet_stem_f32(const float* frames, const float* w_k64, const float* bias, float* out, int32_t T, int32_t H,
+                        int32_t W, tceStream stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem, channels-last [T,H,W,C] -> [T,(H-1)/2+1,(W-1)/2+1,C]. */
+int tce_maxpool3x3s2_cl_f32(const float* x, float* out, int32_t T, int32_t H, int32_t W, int32_t C, tceStream stream);
 
 /* Swin PatchEmbed: frames NCHW [T,3,H,W] -> zero-pad to x4 -> 4x4/s4 conv (w [C,3,4,4]) -> LayerNorm(C).
  * out [T*Hp*Wp, C] token-major.  Reference: swin_transformer.py:427-443. */

@@ -13,6 +13,9 @@ BACKBONES = {
     "video_swin_t_p4w7": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), video=True),
     "video_swin_s_p4w7": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), video=True),
     "video_swin_b_p4w7": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), video=True),
+    # models/backbone.py:59-101 (torchvision bottleneck ResNets; BASELINE config 1 = resnet50)
+    "resnet50": dict(resnet_blocks=(3, 4, 6, 3)),
+    "resnet101": dict(resnet_blocks=(3, 4, 23, 3)),
 }
 
 
@@ -23,6 +26,7 @@ class ModelConfig:
     depths: Tuple[int, ...] = (2, 2, 6, 2)
     num_heads: Tuple[int, ...] = (3, 6, 12, 24)
     video: bool = False
+    resnet_blocks: Tuple[int, ...] = ()  # non-empty: bottleneck ResNet backbone instead of Swin
     window_size: int = 7
     video_window: Tuple[int, int, int] = (8, 7, 7)
     mlp_ratio: float = 4.0
@@ -49,7 +53,13 @@ class ModelConfig:
     text_hidden: int = 768
 
     @property
+    def is_resnet(self):
+        return len(self.resnet_blocks) > 0
+
+    @property
     def num_channels(self):
+        if self.is_resnet:  # backbone.py:68
+            return [256, 512, 1024, 2048]
         return [self.embed_dim * 2 ** i for i in range(len(self.depths))]
 
     @property
@@ -65,8 +75,11 @@ def config_from_args(args) -> ModelConfig:
     name = getattr(args, "backbone", "swin_t_p4w7")
     if name not in BACKBONES:
         raise ValueError(f"backbone '{name}' is outside the MI355X hot path (supported: {sorted(BACKBONES)}); "
-                         f"ResNet / X3D are SURVEY.md section 8 out-of-scope rows")
-    b = BACKBONES[name]
+                         f"X3D is not a SURVEY.md section 8 row")
+    b = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), video=False, resnet_blocks=())
+    b.update(BACKBONES[name])
+    if b["resnet_blocks"] and getattr(args, "dilation", False):
+        raise NotImplementedError("--dilation (DC5) is not part of any BASELINE config")
     if getattr(args, "two_stage", False):
         raise AssertionError("args.two_stage must be false!")  # tce_rvos.py:102
     if getattr(args, "binary", False):
@@ -85,7 +98,7 @@ def config_from_args(args) -> ModelConfig:
         raise NotImplementedError("--no_rel_coord is not supported by the mask-head kernel")
     return ModelConfig(
         backbone=name, embed_dim=b["embed_dim"], depths=tuple(b["depths"]), num_heads=tuple(b["num_heads"]),
-        video=b["video"], hidden_dim=getattr(args, "hidden_dim", 256), nheads=getattr(args, "nheads", 8),
+        video=b["video"], resnet_blocks=tuple(b["resnet_blocks"]), hidden_dim=getattr(args, "hidden_dim", 256), nheads=getattr(args, "nheads", 8),
         num_feature_levels=getattr(args, "num_feature_levels", 4), enc_layers=getattr(args, "enc_layers", 4),
         dec_layers=getattr(args, "dec_layers", 4), dim_feedforward=getattr(args, "dim_feedforward", 2048),
         enc_n_points=getattr(args, "enc_n_points", 4), dec_n_points=getattr(args, "dec_n_points", 4),
@@ -176,14 +189,17 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
         ln(f"input_proj.{l}.1", d)
     # backbone
     b = "backbone.0.body"
-    if cfg.video:
+    if cfg.is_resnet:
+        _resnet_shapes(S, cfg, b)
+    elif cfg.video:
         S[b + ".patch_embed.proj.weight"] = (cfg.embed_dim, 3, 1, 4, 4)
     else:
         S[b + ".patch_embed.proj.weight"] = (cfg.embed_dim, 3, 4, 4)
-    S[b + ".patch_embed.proj.bias"] = (cfg.embed_dim,)
-    ln(b + ".patch_embed.norm", cfg.embed_dim)
+    if not cfg.is_resnet:
+        S[b + ".patch_embed.proj.bias"] = (cfg.embed_dim,)
+        ln(b + ".patch_embed.norm", cfg.embed_dim)
     ws = cfg.window_size
-    for i, depth in enumerate(cfg.depths):
+    for i, depth in enumerate(() if cfg.is_resnet else cfg.depths):
         c = ch[i]
         for j in range(depth):
             p = f"{b}.layers.{i}.blocks.{j}"
@@ -204,7 +220,7 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
             p = f"{b}.downsamples.{i}" if cfg.video else f"{b}.layers.{i}.downsample"
             lin(p + ".reduction", 2 * c, 4 * c, bias=False)
             ln(p + ".norm", 4 * c)
-    if not cfg.video:
+    if not cfg.video and not cfg.is_resnet:
         for i in range(len(cfg.depths)):
             ln(f"{b}.norm{i}", ch[i])
     lin("resizer.fc", d, cfg.text_hidden)
@@ -234,12 +250,41 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     return S
 
 
+FROZEN_BN_LEAVES = ("weight", "bias", "running_mean", "running_var")  # buffers, not parameters (backbone.py:31-34)
+
+
+def _resnet_shapes(S, cfg, b):
+    """torchvision bottleneck ResNet under IntermediateLayerGetter (backbone.py:64-74: conv1, bn1, layer1..4; fc and
+    avgpool are dropped), every norm a FrozenBatchNorm2d."""
+    def bn(pre, c):
+        for leaf in FROZEN_BN_LEAVES:
+            S[f"{pre}.{leaf}"] = (c,)
+
+    S[b + ".conv1.weight"] = (64, 3, 7, 7)
+    bn(b + ".bn1", 64)
+    cin = 64
+    for li, blocks in enumerate(cfg.resnet_blocks):
+        width = 64 * 2 ** li
+        for j in range(blocks):
+            p = f"{b}.layer{li + 1}.{j}"
+            S[p + ".conv1.weight"] = (width, cin, 1, 1)
+            bn(p + ".bn1", width)
+            S[p + ".conv2.weight"] = (width, width, 3, 3)
+            bn(p + ".bn2", width)
+            S[p + ".conv3.weight"] = (width * 4, width, 1, 1)
+            bn(p + ".bn3", width * 4)
+            if j == 0:
+                S[p + ".downsample.0.weight"] = (width * 4, cin, 1, 1)
+                bn(p + ".downsample.1", width * 4)
+            cin = width * 4
+
+
 def index_buffers(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     """Integer buffers the reference registers (relative_position_index) -- kept in the state dict for key
     compatibility; the kernels compute the index analytically."""
     B = OrderedDict()
     b = "backbone.0.body"
-    for i, depth in enumerate(cfg.depths):
+    for i, depth in enumerate(() if cfg.is_resnet else cfg.depths):
         for j in range(depth):
             if cfg.video:
                 n = cfg.video_window[0] * cfg.video_window[1] * cfg.video_window[2]

@@ -255,7 +255,7 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   TCE_CHECK_ARG(a.ldw % 4 == 0 && a.ldw >= a.K, "tce_gemm_f32: ldw=%d must be >= K and a multiple of 4", a.ldw);
   TCE_CHECK_ARG(a.ldc >= a.N, "tce_gemm_f32: ldc=%d < N=%d", a.ldc, a.N);
   TCE_CHECK_ARG(a.res_mode == 0 || (a.res && a.ldres >= a.N), "tce_gemm_f32: res_mode set but res/ldres invalid");
-  TCE_CHECK_ARG(a.act >= 0 && a.act <= 2 && a.res_mode >= 0 && a.res_mode <= 2, "tce_gemm_f32: bad act/res_mode");
+  TCE_CHECK_ARG(a.act >= 0 && a.act <= 3 && a.res_mode >= 0 && a.res_mode <= 2, "tce_gemm_f32: bad act/res_mode");
   if (a.batch <= 0) a.batch = 1;
   if (a.conv) {
     TCE_CHECK_ARG(a.A2 == nullptr, "tce_gemm_f32: A2 is not supported with conv");

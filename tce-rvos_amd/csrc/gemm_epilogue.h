@@ -25,6 +25,7 @@ __device__ __forceinline__ void tce_epi_store(const f32x16& x, const float bv, c
     if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (RES == 1) v += rv[r];
     if (RES == 2) v *= rv[r];
+    if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
     if (row < M) C[(long long)row * ldc + col] = v;
   }
 }
@@ -59,6 +60,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
         if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         if (RES == 1) v += rv[g][c];
         if (RES == 2) v *= rv[g][c];
+        if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
         o[c] = v;
       }
       *reinterpret_cast<f32x4*>(crow + n0 + 8 * g) = o;
@@ -75,6 +77,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
           if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
           if (RES == 1) v += rrow[n];
           if (RES == 2) v *= rrow[n];
+          if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
           crow[n] = v;
         }
       }
@@ -136,6 +139,7 @@ __device__ __forceinline__ void tce_epi_store_lds(const f32x16& x, float* __rest
       if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
       if (RES == 1) v += rv[it][c];
       if (RES == 2) v *= rv[it][c];
+      if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
       o[c] = v;
     }
     if (row < M) {
@@ -168,5 +172,8 @@ __device__ __forceinline__ bool tce_epi_vec_ok(const float* C, long long ldc, co
     case 5: BODY(1, 2); break;                \
     case 6: BODY(2, 0); break;                \
     case 7: BODY(2, 1); break;                \
-    default: BODY(2, 2); break;               \
+    case 8: BODY(2, 2); break;                \
+    case 9: BODY(3, 0); break;                \
+    case 10: BODY(3, 1); break;               \
+    default: BODY(3, 2); break;               \
   }

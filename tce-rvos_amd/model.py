@@ -99,7 +99,10 @@ class ReferFormer(nn.Module):
         shapes = param_shapes(cfg)
         for key, shape in shapes.items():
             node, leaf = self._node_for(key)
-            node.register_parameter(leaf, nn.Parameter(synth_tensor(key, shape, init_salt), requires_grad=True))
+            if cfg.is_resnet and is_frozen_bn_key(key):  # FrozenBatchNorm2d holds buffers (backbone.py:31-34)
+                node.register_buffer(leaf, synth_tensor(key, shape, init_salt))
+            else:
+                node.register_parameter(leaf, nn.Parameter(synth_tensor(key, shape, init_salt), requires_grad=True))
         for key, shape in index_buffers(cfg).items():
             node, leaf = self._node_for(key)
             node.register_buffer(leaf, self._rel_index(cfg))
@@ -205,11 +208,34 @@ class ReferFormer(nn.Module):
                     w[pre + "qk.w"], w[pre + "qk.b"] = W[:2 * d], B[:2 * d]
                 if v_is_conv(sd[k]) and sd[k].shape[-1] == 3:
                     w[k + ":cl"] = sd[k].detach().permute(0, 2, 3, 1).reshape(sd[k].shape[0], -1).contiguous()
+            if cfg.is_resnet:
+                self._pack_resnet(sd, w)
             if cfg.video:
                 w["backbone.0.body.patch_embed.proj.weight:2d"] = \
                     sd["backbone.0.body.patch_embed.proj.weight"].detach().squeeze(2).contiguous()
         self._packed = w
         return w
+
+    @staticmethod
+    def _pack_resnet(sd, w):
+        """FrozenBatchNorm2d (backbone.py:46-56) is an affine map per output channel: fold its scale into the
+        convolution in front of it and keep its bias as the GEMM bias.  conv -> ":f" = [Cout, kh*kw*Cin] with
+        k = (ky*kw+kx)*Cin + c (implicit-GEMM order); the stem -> [147, 64] with k = (c*7+ky)*7+kx."""
+        for k in list(sd):
+            if not (k.startswith("backbone.0.body.") and k.endswith(".weight") and sd[k].dim() == 4):
+                continue
+            pre = k[:-len(".weight")]
+            if pre.endswith("downsample.0"):
+                bn = pre[:-1] + "1"
+            else:
+                bn = pre[:pre.rfind(".") + 1] + "bn" + pre[-1]
+            scale = sd[bn + ".weight"].detach() * (sd[bn + ".running_var"].detach() + 1e-5).rsqrt()
+            w[pre + ":b"] = (sd[bn + ".bias"].detach() - sd[bn + ".running_mean"].detach() * scale).contiguous()
+            wf = sd[k].detach() * scale.view(-1, 1, 1, 1)
+            if pre.endswith("body.conv1"):
+                w[pre + ":f"] = wf.reshape(64, 147).t().contiguous()
+            else:
+                w[pre + ":f"] = wf.permute(0, 2, 3, 1).reshape(wf.shape[0], -1).contiguous()
 
     # ---------------------------------------------------------------- per-shape constants
     def _shape_consts(self, T, H0, W0, device):
@@ -420,6 +446,11 @@ class ReferFormer(nn.Module):
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
             ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res), frames)
         return self._replay(ent, (frames, text_hidden, text_pooled))
+
+
+def is_frozen_bn_key(key):
+    from .weights import _FBN
+    return _FBN.search(key) is not None
 
 
 def v_is_conv(t):

@@ -6,7 +6,7 @@ import torch
 
 from ._lib import GemmArgs, check, lib
 
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_AFTER_RES = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_MUL = 0, 1, 2
 
 
@@ -145,7 +145,8 @@ def gemm_batched(a, w, out, bias=None, act=ACT_NONE):
     return out
 
 
-def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT_NONE, out=None, alloc=None):
+def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT_NONE, out=None, alloc=None, res=None,
+              res_mode=RES_NONE):
     """Channels-last convolution as implicit GEMM.  x [T*H*W, Cin]; w_packed [N, kh*kw*Cin] with
     k = (ky*kw+kx)*Cin + c.  Returns [T*Ho*Wo, N]."""
     _chk(x, "x")
@@ -162,7 +163,10 @@ def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT
     g.lda, g.ldw, g.ldc = Cin, kh * kw * Cin, N
     if bias is not None:
         g.bias = bias.data_ptr()
-    g.act, g.batch, g.conv = act, 1, 1
+    if res_mode != RES_NONE:
+        _chk(res, "res")
+        g.res, g.ldres = res.data_ptr(), N
+    g.act, g.res_mode, g.batch, g.conv = act, res_mode, 1, 1
     g.T, g.H, g.Wd, g.Cin, g.Ho, g.Wo = T, H, W, Cin, Ho, Wo
     g.kh, g.kw, g.stride, g.pad = kh, kw, stride, pad
     _gemm_launch(g)
@@ -191,6 +195,29 @@ def groupnorm_cl(x, gamma, beta, T, HW, Cn, G, eps=1e-5, relu=False, out=None, w
     check(lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW,
                                   Cn, G, eps, 1 if relu else 0, _stream()), "tce_groupnorm_f32")
     return out
+
+
+def resnet_stem(frames, w_k64, bias, out=None, alloc=None):
+    """conv 7x7/s2/p3 (3 -> 64) + folded FrozenBatchNorm2d + ReLU; frames NCHW -> channels-last [T*Ho*Wo, 64]."""
+    _chk(frames, "frames")
+    T, c3, H, W = frames.shape
+    if c3 != 3 or not frames.is_contiguous():
+        raise ValueError("resnet_stem: frames must be contiguous [T,3,H,W]")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = alloc(T * Ho * Wo, 64) if alloc else torch.empty(T * Ho * Wo, 64, dtype=torch.float32, device=frames.device)
+    check(lib().tce_resnet_stem_f32(frames.data_ptr(), w_k64.data_ptr(), bias.data_ptr(), out.data_ptr(), T, H, W,
+                                    _stream()), "tce_resnet_stem_f32")
+    return out, Ho, Wo
+
+
+def maxpool3x3s2_cl(x, T, H, W, Cn, out=None, alloc=None):
+    _chk(x, "x")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = alloc(T * Ho * Wo, Cn) if alloc else torch.empty(T * Ho * Wo, Cn, dtype=torch.float32, device=x.device)
+    check(lib().tce_maxpool3x3s2_cl_f32(x.data_ptr(), out.data_ptr(), T, H, W, Cn, _stream()), "tce_maxpool3x3s2_cl_f32")
+    return out, Ho, Wo
 
 
 def patch_embed(frames, w, b, gamma, beta, eps=1e-5, out=None, alloc=None):

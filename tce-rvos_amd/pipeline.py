@@ -9,7 +9,7 @@ independent for un-padded clips and are shared by all frames through frame-batch
 import torch
 
 from . import ops
-from .ops import ACT_GELU, ACT_RELU, RES_ADD, RES_MUL, gemm_ex
+from .ops import ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RES, RES_ADD, RES_MUL, gemm_ex
 
 D = 256
 NH = 8
@@ -71,7 +71,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     ff = cfg.dim_feedforward
 
     # ------------------------------------------------------------------ backbone
-    feats = _swin_backbone(model, frames, ar, sizes)
+    feats = (_resnet_backbone if cfg.is_resnet else _swin_backbone)(model, frames, ar, sizes)
 
     # ------------------------------------------------------------------ text (FeatureResizer :616-635)
     if text_fork is not None:
@@ -370,6 +370,46 @@ def _swin_backbone(model, frames, ar, sizes):
             ar.release(m0)
             x = x_next
             C *= 2
+    return feats
+
+
+def _resnet_backbone(model, frames, ar, sizes):
+    """models/backbone.py:76-85 over torchvision's bottleneck ResNet (row A11): returns layer1..layer4 maps,
+    token-major [T*h*w, 256/512/1024/2048].  Each FrozenBatchNorm2d is folded into the convolution before it
+    (model._pack_resnet), so a bottleneck is three (block 0: four) GEMM launches: 1x1 + ReLU, 3x3 (carrying the
+    stride, "v1.5") + ReLU as implicit GEMM, 1x1 + identity + ReLU in one epilogue."""
+    cfg, w = model.cfg, model._packed
+    A = ar.alloc
+    T = frames.shape[0]
+    b = "backbone.0.body."
+    feats = [A(T * h * ww, c) for (h, ww), c in zip(sizes, cfg.num_channels)]
+    m_all = ar.mark()
+    stem, H1, W1 = ops.resnet_stem(frames, w[b + "conv1:f"], w[b + "conv1:b"], alloc=A)
+    x, H, W = ops.maxpool3x3s2_cl(stem, T, H1, W1, 64, alloc=A)
+    assert (H, W) == tuple(sizes[0])
+    cin = 64
+    for li, blocks in enumerate(cfg.resnet_blocks):
+        width = 64 * 2 ** li
+        Ho, Wo = sizes[li]
+        for j in range(blocks):
+            p = f"{b}layer{li + 1}.{j}."
+            stride = 2 if (j == 0 and li > 0) else 1
+            out = feats[li] if j == blocks - 1 else A(T * Ho * Wo, 4 * width)
+            m0 = ar.mark()
+            if j == 0:
+                idt, _, _ = ops.conv2d_cl(x, w[p + "downsample.0:f"], T, H, W, cin, 1, 1, stride, 0,
+                                          bias=w[p + "downsample.0:b"], alloc=A)
+            else:
+                idt = x
+            y1 = A(T * H * W, width)
+            gemm_ex(x, w[p + "conv1:f"], y1, T * H * W, width, cin, cin, cin, width, bias=w[p + "conv1:b"], act=ACT_RELU)
+            y2, _, _ = ops.conv2d_cl(y1, w[p + "conv2:f"], T, H, W, width, 3, 3, stride, 1, bias=w[p + "conv2:b"],
+                                     act=ACT_RELU, alloc=A)
+            gemm_ex(y2, w[p + "conv3:f"], out, T * Ho * Wo, 4 * width, width, width, width, 4 * width,
+                    bias=w[p + "conv3:b"], act=ACT_RELU_AFTER_RES, res=idt, ldres=4 * width, res_mode=RES_ADD)
+            ar.release(m0)
+            x, H, W, cin = out, Ho, Wo, 4 * width
+    ar.release(m_all)
     return feats
 
 

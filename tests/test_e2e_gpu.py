@@ -80,6 +80,27 @@ def test_swin_t_config2_fullsize_matches_reference(models):
     _compare(out, fx, 2e-2)
 
 
+def test_resnet50_small_matches_reference(models):
+    """Row A11 (ResNet-50 + FrozenBatchNorm2d backbone) against outputs of the reference itself."""
+    fx, out, _ = _run(models, "e2e_resnet50_small.npz", "resnet50")
+    _compare(out, fx, 5e-3)
+    assert (out["memory"].cpu() - torch.from_numpy(fx["stage_memory"])).abs().max().item() < 2e-3
+
+
+def test_resnet50_config1_fullsize_matches_reference(models):
+    """BASELINE config 1: ResNet-50, T=1, 360x640 -- through the forward boundary, graph replay included."""
+    fx, out, model = _run(models, "e2e_resnet50_cfg1.npz", "resnet50")
+    _compare(out, fx, 2e-2)
+    T, H, W = (int(v) for v in fx["thw"])
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    ids = torch.randint(3, 50000, (1, 9))
+    a = model([frames], ids, [{"size": torch.tensor([H, W])}])
+    b = model([frames], ids, [{"size": torch.tensor([H, W])}])
+    torch.cuda.synchronize()
+    assert torch.equal(a["pred_masks"], b["pred_masks"])
+    assert a["pred_masks"].shape == (1, 1, 5, 90, 160)
+
+
 def test_forward_boundary_matches_oracle_and_is_deterministic(models):
     """Through model(samples, captions, targets) with token ids; second call must be bit-identical
     (the arena / cached constants must not leak state between clips)."""

@@ -48,12 +48,13 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.lib()
 
 
-@pytest.mark.parametrize("bb,man", [("swin_t_p4w7", "statedict_swin_t.json"), ("video_swin_t_p4w7", "statedict_vswin_t.json")])
+@pytest.mark.parametrize("bb,man", [("swin_t_p4w7", "statedict_swin_t.json"), ("video_swin_t_p4w7", "statedict_vswin_t.json"),
+                                    ("resnet50", "statedict_resnet50.json")])
 def test_param_manifest_matches_reference_state_dict(bb, man):
-    from tce_rvos_amd.config import BACKBONES, ModelConfig, index_buffers, param_shapes
+    import argparse
+    from tce_rvos_amd.config import config_from_args, index_buffers, param_shapes
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", man)))
-    b = BACKBONES[bb]
-    cfg = ModelConfig(backbone=bb, video=b["video"], embed_dim=b["embed_dim"], depths=b["depths"], num_heads=b["num_heads"])
+    cfg = config_from_args(argparse.Namespace(backbone=bb, with_box_refine=True, binary=True, f_token=8, qtrans=True))
     mine = dict(param_shapes(cfg))
     mine.update(index_buffers(cfg))
     for k in list(mine):
@@ -108,7 +109,9 @@ def test_unsupported_configs_fail_loudly():
     import argparse
     from tce_rvos_amd import build_model
     with pytest.raises(ValueError):
-        build_model(argparse.Namespace(backbone="resnet50"))
+        build_model(argparse.Namespace(backbone="x3d_m"))
+    with pytest.raises(NotImplementedError):
+        build_model(argparse.Namespace(backbone="resnet50", dilation=True))
     with pytest.raises(AssertionError):
         build_model(argparse.Namespace(backbone="swin_t_p4w7", two_stage=True))
 

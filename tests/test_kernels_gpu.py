@@ -395,3 +395,44 @@ def test_gemm_presplit_dma_prototype(ops, M, N, K):
     check(lib().tce_gemm_h2_f32(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(),
                                 db.data_ptr(), None, out.data_ptr(), M, N, K, K, K, N, 0, 2, 0, 0, ops._stream()), "h2")
     close(out, F.gelu(F.linear(a_eff, w, b)), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("T,H,W", [(1, 72, 100), (2, 37, 61), (1, 360, 640)])
+def test_resnet_stem_and_maxpool(ops, T, H, W):
+    """conv 7x7/s2/p3 + folded frozen BN + ReLU, then MaxPool2d(3, 2, 1), vs PyTorch on the CPU (oracle ops)."""
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(T, 3, H, W, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, wt, b, stride=2, padding=3))
+    refp = F.max_pool2d(ref, 3, stride=2, padding=1)
+    out, Ho, Wo = ops.resnet_stem(x.cuda(), wt.reshape(64, 147).t().contiguous().cuda(), b.cuda())
+    assert (Ho, Wo) == tuple(ref.shape[-2:])
+    got = out.view(T, Ho, Wo, 64).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 2e-5
+    pooled, Hp, Wp = ops.maxpool3x3s2_cl(out, T, Ho, Wo, 64)
+    assert (Hp, Wp) == tuple(refp.shape[-2:])
+    gotp = pooled.view(T, Hp, Wp, 64).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(gotp, F.max_pool2d(got, 3, stride=2, padding=1))  # the pool itself is exact
+    assert (gotp - refp).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("stride,k,cin,cout", [(1, 1, 64, 256), (2, 1, 256, 512), (2, 3, 128, 128), (1, 3, 64, 64)])
+def test_conv_with_identity_and_relu_after_residual(ops, stride, k, cin, cout):
+    """ResNet bottleneck epilogue: relu(conv(x) + bias + identity) (act 3, res_mode 1), strided 1x1 / 3x3."""
+    g = torch.Generator().manual_seed(cin + k)
+    T, H, W = 2, 23, 31
+    x = torch.randn(T, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    y = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+    idt = torch.randn(y.shape, generator=g)
+    ref = F.relu(y + idt)
+    xcl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().cuda()
+    wcl = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    icl = idt.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().cuda()
+    out, Ho, Wo = ops.conv2d_cl(xcl, wcl, T, H, W, cin, k, k, stride, k // 2, bias=b.cuda(), act=ops.ACT_RELU_AFTER_RES,
+                                res=icl, res_mode=ops.RES_ADD)
+    got = out.view(T, Ho, Wo, cout).permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-4
