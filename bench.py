@@ -201,12 +201,15 @@ def main():
 
     C = C_saved
     if rank == 0:
+        known = {("resnet50", 1, 360, 640): "BASELINE config 1", ("swin_t_p4w7", 5, 360, 640): "BASELINE config 2",
+                 ("video_swin_t_p4w7", 8, 384, 640): "BASELINE config 3", ("swin_b_p4w7", 10, 480, 854): "BASELINE config 5"}
+        cfg_name = known.get((args.backbone, T, H, W), "not a BASELINE config")
         clips_total = args.steps * world * C
         line = {"metric": METRIC, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.gemm_mode == "f32" else "f32 (3xf16-split MFMA, f32 accumulate)", "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
-                                       f"flags --with_box_refine --binary --f_token 8 --qtrans (BASELINE config 2)",
+                                       f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
                            "clips_per_step": world * C, "clips_in_flight_per_gpu": C,
                            "parallelism": f"clip-sharded x{world}" +
                                                                    (" + RCCL all_gather(pred_masks)" if world > 1 else "")},

@@ -139,7 +139,12 @@ def test_video_swin_t_small_matches_reference(models):
 
 
 @pytest.mark.parametrize("backbone,T,H,W", [("video_swin_t_p4w7", 8, 384, 640),   # BASELINE config 3
-                                            ("swin_b_p4w7", 10, 480, 854)])      # BASELINE config 5 (fp16 MFMA, f32 acc)
+                                            ("swin_b_p4w7", 10, 480, 854),       # BASELINE config 5 (fp16 MFMA, f32 acc)
+                                            # long clips (DAVIS clip_size 32, inference_davis.py:209-213):
+                                            # FTF token sequence T*8 = 256, IQT over 32 frames, MSDA with N = 32
+                                            ("swin_t_p4w7", 32, 120, 216),
+                                            # Video-Swin beyond one temporal window: T=19 pads to 24, temporal shift 4
+                                            ("video_swin_t_p4w7", 19, 96, 160)])
 def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
     """BASELINE configs 3 and 5 at full size: HIP path vs the CPU oracle (itself pinned to the reference by the
     golden fixtures) on the same synthetic weights / inputs."""
@@ -154,6 +159,10 @@ def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
     sd = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
     b = __import__("tce_rvos_amd.config", fromlist=["BACKBONES"]).BACKBONES[backbone]
     cfg = O.OracleConfig(backbone=backbone, embed_dim=b["embed_dim"], depths=b["depths"], num_heads=b["num_heads"])
+    # same clip through the public boundary (graph capture + replay at this shape)
+    ids = torch.randint(3, 50000, (1, 12), generator=g)
+    via_boundary = model([frames.cuda()], ids, [{"size": torch.tensor([H, W])}])
+    assert via_boundary["pred_masks"].shape == (1, T, 5, (H + 3) // 4, (W + 3) // 4)
     with torch.no_grad():
         ref = O.forward(sd, cfg, frames, hid[None], pooled[None], img_size=(H, W))
     diffs = {k: (out[k].cpu() - ref[k]).abs().max().item() for k in ("pred_logits", "pred_boxes", "pred_masks")}
