@@ -191,6 +191,16 @@ int tce_select_masks_u8(const float* logits, const float* masks, uint8_t* out, i
                         int32_t Q, int32_t K, int32_t h, int32_t w, int32_t H0, int32_t W0, float threshold,
                         tceStream stream);
 
+/* Clip front-end (inference_ytvos.py:38-42,279-287; inference_davis.py:39-43): T.Resize(360) = Pillow
+ * Image.resize(BILINEAR) in 8-bit fixed point, then ToTensor + Normalize.  coef [n_out, ksize] int32 (22 fractional
+ * bits) and bounds [n_out, 2] = (first input index, taps) are Pillow's precompute_coeffs/normalize_coeffs_8bpc
+ * tables (host: tce_rvos_amd/frontend.py).  Pass 1: in [rows, Win, 3] u8 -> tmp [rows, Wout, 3] u8.  Pass 2:
+ * tmp [T, Hin, W, 3] u8 -> out [T, 3, Hout, W] f32 through lut[3][256] = ((v/255) - mean[c]) / std[c]. */
+int tce_resize_h_u8(const uint8_t* in, const int32_t* coef, const int32_t* bounds, uint8_t* tmp, int64_t rows,
+                    int32_t Win, int32_t Wout, int32_t ksize, tceStream stream);
+int tce_resize_v_norm_f32(const uint8_t* tmp, const int32_t* coef, const int32_t* bounds, const float* lut, float* out,
+                          int32_t T, int32_t Hin, int32_t W, int32_t Hout, int32_t ksize, tceStream stream);
+
 /* RoBERTa text encoder (models/tce_rvos.py:406-424; HuggingFace RobertaModel arithmetic) -- the pieces not covered
  * by tce_gemm_f32 / tce_layernorm_f32:
  *   tce_embed_ln_f32     out[t] = LayerNorm(word[ids[t]] + position[pos_ids[t]] + token_type[0])   (ids int64, device)

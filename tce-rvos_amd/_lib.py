@@ -43,6 +43,8 @@ SIGNATURES = {
     "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),
     "tce_resnet_stem_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_maxpool3x3s2_cl_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
+    "tce_resize_h_u8": (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, c_f]),
+    "tce_resize_v_norm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, c_f]),
     "tce_patch_embed_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
     "tce_window_attn_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_window_attn3d_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),

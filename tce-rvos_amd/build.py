@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm_f16x3.hip", "gemm_h2.hip", "norm.hip", "attn.hip", "msda.hip", "misc.hip", "text.hip", "resnet.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm_f16x3.hip", "gemm_h2.hip", "norm.hip", "attn.hip", "msda.hip", "misc.hip", "text.hip", "resnet.hip", "frontend.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
