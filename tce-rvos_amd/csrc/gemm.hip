@@ -229,7 +229,9 @@ static int select_tile_ex(int M, int N, int K, int batch, int conv) {
   if (g_gemm_mode == 1) {
     // measured on MI355X (tools/gemm_bench.py): the 8-wave 256x128 tile wins once it fills the chip 1.5x and the
     // problem is wide or deep; 128x128 for the big implicit-GEMM convolutions; the small tiles elsewhere
-    if (n256 >= 384 && (N >= 512 || K >= 1024) && !conv) return 256128;
+    // (tools/gemm_shape_sweep.py over every launch of a config-2 clip: deep-K / wide problems already prefer the
+    // 8-wave tile at ~0.65 waves of the chip, e.g. 24100x256x2048 90 us vs 100 us, 4600x1536x384 31 us vs 37 us)
+    if (!conv && ((n256 >= 384 && N >= 512) || (n256 >= 128 && K >= 1024) || (n256 >= 160 && N >= 1024 && K >= 384))) return 256128;
     if (conv && n128 >= 256) return 128128;
     if (n12864 >= 384 && M > 64) return 12864;
     return 6464;
