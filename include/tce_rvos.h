@@ -61,6 +61,9 @@ int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
 int tce_debug_set_stamp_buffer(long long* dev_buf);
 /* same for the prototype GEMM (tce_gemm_h2_f32): >= 256*8*8 int64, per-wave phase sums */
 int tce_debug_h2_set_stamp_buffer(long long* dev_buf);
+/* diagnostic: bare fp16 MFMA loop (12 MFMAs x iters per wave) on `blocks` workgroups of `threads` threads; out needs
+ * blocks*threads floats.  mode 0 registers only, 1/2 with the GEMM's LDS fragment feed, 3 plus a barrier per 24 MFMAs. */
+int tce_debug_mfma_peak(float* out, int32_t blocks, int32_t threads, int32_t iters, int32_t mode, tceStream stream);
 int tce_debug_set_epilogue(int32_t lds_staged); /* tuning aid: 1 (default) LDS-staged coalesced stores, 0 direct */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);

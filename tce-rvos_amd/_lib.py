@@ -33,6 +33,7 @@ SIGNATURES = {
     "tce_gemm_force_tile": (i32, [i32]),
     "tce_debug_set_stamp_buffer": (i32, [c_f]),
     "tce_debug_h2_set_stamp_buffer": (i32, [c_f]),
+    "tce_debug_mfma_peak": (i32, [c_f, i32, i32, i32, i32, c_f]),
     "tce_debug_set_epilogue": (i32, [i32]),
     "tce_set_gemm_mode": (i32, [i32]),
     "tce_get_gemm_mode": (i32, []),

@@ -1,15 +1,20 @@
-// PROTOTYPE (tools/gemm_h2_bench.py; not on the product path): the split-fp16 GEMM with PRE-SPLIT operands and LDS-DMA
-// staging.  Measured (MI355X): correct to the same error as the shipped kernel but only 0-10 % faster, and with the
-// MFMAs removed it still needs ~80 % of its time -- the K loop of these fp32-activation GEMMs is bound by the
-// operand feed (64-128 B pieces of many rows per slice), not by VALU conversion, LDS or the matrix pipe; the lever is
-// a K-panel-blocked activation layout / fewer bytes, not the staging mechanism.
+// PROTOTYPE (tools/gemm_h2_bench.py, tools/gemm_h2_stamps.py, tools/mfma_peak.py; not on the product path): the
+// split-fp16 GEMM with PRE-SPLIT operands and LDS-DMA staging, used to find out what bounds the shipped kernel's K loop.
 //
-// Operands arrive as fp16 planes (hi, lo) in HBM -- produced by tce_split_f16_f32 here; in the planned dataflow
-// by the epilogue of whichever kernel produced the tensor -- so a K slice moves HBM/L2 -> LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no conversion VALU, no ds_write) into a 3-stage ring, two slices ahead
-// of the MFMAs, behind counted s_waitcnt vmcnt(N) and one raw s_barrier per slice.  The LDS image is lane-linear
-// per DMA instruction (16 rows x 64 B), so the bank-conflict-free XOR swizzle is applied on the SOURCE address.
-// 256x128 tile, 8 waves (4x2) of 64x64, BK = 32, 48 KiB per stage.
+// Operands arrive as fp16 planes (hi, lo) in HBM -- produced by tce_split_f16_f32 here; in a planned dataflow by the
+// epilogue of whichever kernel produced the tensor -- so a K slice moves HBM/L2 -> LDS with global_load_lds_dwordx4
+// (no VGPR staging, no conversion VALU, no ds_write) into a 3-slot ring, a slice issued two slices before its use,
+// behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per slice placed mid-slice, every fragment read prefetched
+// under the previous half's MFMAs.  The LDS image is lane-linear per DMA instruction (16 rows x 64 B), so the
+// bank-conflict-free XOR swizzle is applied on the SOURCE address.  256x128 tile, 8 waves (4x2) of 64x64, BK = 32,
+// 48 KiB per slot.  A may also be stored K-slice-major [K/32][M][32] (a_slice) so every DMA piece is contiguous.
+//
+// Measured (MI355X): bit-identical results; 0-15 % faster than the shipped register-staged kernel whatever the loop
+// structure.  Removing ALL DMA from the loop leaves 85 % of the time, removing the MFMAs 80 %; the bare MFMA loop of
+// tools/mfma_peak.py (same 8 ds_read_b128 per 12 MFMAs, two waves per SIMD, no memory) sustains 1.6-1.7 PFLOP/s
+// chip-wide (clock-limited: 2.0 PFLOP/s-equivalent per CU when only 190 CUs issue), 1.3-1.6 with a barrier per 24
+// MFMAs -- so both kernels already run at 50-55 % of what the matrix pipe can sustain under this mix, and the
+// remaining gap is barrier phases, not the memory path.
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "../../include/tce_rvos.h"
@@ -73,6 +78,11 @@ __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const i
     src[q] = base + (long long)grow * ld + c * 8;
     dst[q] = (unsigned)(off + row0 * 64);
   }
+  auto issue_one = [&](int kt, int slot, int q) {
+    const bool is_a = (wave + 8 * q) < 32;
+    glds16(src[q] + (long long)kt * (is_a ? p.a_slice : (long long)BK),
+           __builtin_amdgcn_readfirstlane(dst[q] + (unsigned)(slot * STAGE)));
+  };
   auto issue = [&](int kt, int slot) {
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; ++q) {
@@ -117,34 +127,68 @@ __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const i
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][0], fa[ks][i][0], acc[i][j], 0, 0, 0);
       }
   };
-  // Ring discipline: at the top of slice kt this wave's DMAs of slice kt have landed (counted vmcnt leaves the 6
-  // of slice kt+1 in flight), the barrier publishes every wave's share and proves slot (kt+2)%3 -- slice kt-1 --
-  // is no longer read, so slice kt+2 is issued right behind it: two full slices (96 KiB per CU) stay in flight.
+  // Ring discipline (one barrier per slice, placed MID-slice so that nothing the matrix pipe needs is ever fetched
+  // right after it):
+  //   first-half MFMAs of slice kt            (fragments already in registers)
+  //   s_waitcnt vmcnt(6) ; s_barrier          slice kt+1 has landed for every wave (slice kt+2 may still fly);
+  //                                           every wave also holds BOTH halves of slice kt in registers, so
+  //                                           slot kt%3 is free
+  //   ds_read first half of slice kt+1        lands under the second-half MFMAs
+  //   second-half MFMAs of slice kt, the 6 DMA pieces of slice kt+3 (-> slot kt%3) interleaved between them
+  //   ds_read second half of slice kt+1       lands under the first-half MFMAs of slice kt+1
+  // A slice is issued two full slices before it is needed (96 KiB per CU in flight).
   long long* const stamps = (g_h2_stamps && blockIdx.x < 256) ? g_h2_stamps + (blockIdx.x * 8 + wave) * 8 : nullptr;
   long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_begin = 0;
   if (stamps) t_begin = (long long)__builtin_amdgcn_s_memtime();
   issue(0, 0);
   if (nk > 1) issue(1, 1);
+  if (nk > 2) issue(2, 2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_half(smem, 0);
+  read_half(smem, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* st = smem + (kt % NSTAGE) * STAGE;
-    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (stamps) t0 = (long long)__builtin_amdgcn_s_memtime();
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (stamps) t1 = (long long)__builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamps) t2 = (long long)__builtin_amdgcn_s_memtime();
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
-    if (stamps) t3 = (long long)__builtin_amdgcn_s_memtime();
-    read_half(st, 0);
-    read_half(st, 1);
+    long long t0 = 0, t1 = 0, t2 = 0;
     mfma_half(0);
-    mfma_half(1);
-    if (stamps) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (stamps) t0 = (long long)__builtin_amdgcn_s_memtime();
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stamps) t1 = (long long)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const long long t4 = (long long)__builtin_amdgcn_s_memtime();
-      t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2; t_comp += t4 - t3;
+      if (stamps) t2 = (long long)__builtin_amdgcn_s_memtime();
+      read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 0);
+    }
+    // second half: 12 MFMAs with the DMA pieces of slice kt+3 dropped between them
+    const bool more = kt + 3 < nk;
+    const int nslot = kt % NSTAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][1], fa[1][i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][0], fa[1][i][1], acc[i][j], 0, 0, 0);
+        if (more) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one(kt + 3, nslot, 2 * i + j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][0], fa[1][i][0], acc[i][j], 0, 0, 0);
+      }
+    if (more) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_one(kt + 3, nslot, 4);
+      issue_one(kt + 3, nslot, 5);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 1);
+    if (stamps) {
+      t_wait += t1 - t0; t_bar += t2 - t1;
     }
   }
   if (stamps && lane == 0) {
@@ -190,6 +234,53 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+// Diagnostic (tools/mfma_peak.py): what the matrix pipe sustains chip-wide under this GEMM's instruction mix, with no
+// memory system involved -- mode 0: operands in registers; 1: 8 ds_read_b128 per 12 MFMAs (the fragment feed of the
+// 64x64 wave tile); 2: same with three consecutive MFMAs per accumulator; 3: mode 2 + one s_barrier per 24 MFMAs.
+__global__ void __launch_bounds__(512, 1) mfma_peak_kernel(float* out, int iters, int with_lds) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[65536];
+  const int lane = threadIdx.x & 63;
+  h16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(lane * 0.001f + i); b[i] = (_Float16)(1.0f - i * 0.01f); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) reinterpret_cast<float*>(sm)[i] = i * 1e-6f;
+  __syncthreads();
+  const unsigned char* base = sm + (threadIdx.x >> 6) * 4096 + lane * 16;
+  for (int it = 0; it < iters; ++it) {
+    if (with_lds) {  // 8 ds_read_b128 per 12 MFMAs, like the GEMM's fragment feed
+      h16x8 f[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const h16x8*>(base + ((q * 1024 + it * 16) & 3071));
+      if (with_lds == 1) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+          acc[q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[q & 7], f[(q + 3) & 7], acc[q & 3], 0, 0, 0);
+      } else {  // the GEMM's order: three consecutive MFMAs on one accumulator
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+          acc[q / 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[q & 7], f[(q + 3) & 7], acc[q / 3], 0, 0, 0);
+      }
+      if (with_lds == 3 && (it & 1)) __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[q & 3], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int tce_debug_mfma_peak(float* out, int32_t blocks, int32_t threads, int32_t iters, int32_t mode,
+                                   tceStream stream) {
+  TCE_CHECK_ARG(out && blocks > 0 && blocks <= 4096 && (threads == 256 || threads == 512) && iters > 0 && mode >= 0 && mode <= 3,
+                "tce_debug_mfma_peak: bad arguments");
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, out, iters, mode);
+  TCE_CHECK_LAUNCH("tce_debug_mfma_peak");
+  return TCE_OK;
+}
 
 extern "C" int tce_debug_h2_set_stamp_buffer(long long* dev_buf) {
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_h2_stamps), &dev_buf, sizeof(dev_buf));
