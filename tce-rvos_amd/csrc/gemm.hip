@@ -285,3 +285,62 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   TCE_CHECK_LAUNCH("tce_gemm_f32");
   return TCE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-K for skinny, deep problems (M <= a tile or two, K in the thousands: the RoBERTa projections at 32 tokens,
+// the decoder FFNs on 25 rows): a plain launch has N/64 workgroups streaming the whole K extent of the weights one
+// after the other (9.4 MB at ~0.2 TB/s for 32x768x3072).  The K extent is cut into `splits` chunks that run as the
+// batch dimension of the same kernel into workspace[splits][M][N]; a second kernel sums the partials and applies the
+// epilogue (bias, activation, residual) exactly as the GEMM epilogue would.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, float* __restrict__ C,
+                                                            const int M, const int N, const int splits, const int ldc,
+                                                            const int ldres, const int act, const int res_mode) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i >= (long long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+  const long long plane = (long long)M * N;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)m * N + n);
+  for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * plane + (long long)m * N + n);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = v[c] + (bias ? bias[n + c] : 0.f);
+    if (act == 1) x = fmaxf(x, 0.f);
+    if (act == 2) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    if (res_mode == 1) x += res[(long long)m * ldres + n + c];
+    if (res_mode == 2) x *= res[(long long)m * ldres + n + c];
+    if (act == 3) x = fmaxf(x, 0.f);
+    C[(long long)m * ldc + n + c] = x;
+  }
+}
+}  // namespace
+
+extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspace, tceStream stream) {
+  TCE_CHECK_ARG(args != nullptr && workspace != nullptr, "tce_gemm_splitk_f32: null args/workspace");
+  tceGemmArgs a = *args;
+  TCE_CHECK_ARG(splits >= 1 && splits <= 64, "tce_gemm_splitk_f32: splits=%d out of range", splits);
+  TCE_CHECK_ARG(!a.conv && a.batch <= 1, "tce_gemm_splitk_f32: plain un-batched GEMMs only");
+  TCE_CHECK_ARG(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.K > 0 && a.K % (splits * BK) == 0,
+                "tce_gemm_splitk_f32: N=%d must be a multiple of 4 and K=%d a multiple of splits*%d", a.N, a.K, BK);
+  TCE_CHECK_ARG(a.C && tce_aligned16(workspace), "tce_gemm_splitk_f32: null C / unaligned workspace");
+  TCE_CHECK_ARG(a.ldc >= a.N && (a.res_mode == 0 || (a.res && a.ldres >= a.N)), "tce_gemm_splitk_f32: bad ldc/res");
+  TCE_CHECK_ARG(a.act >= 0 && a.act <= 3 && a.res_mode >= 0 && a.res_mode <= 2, "tce_gemm_splitk_f32: bad act/res_mode");
+  tceGemmArgs g = a;
+  const int kc = a.K / splits;
+  g.K = kc;
+  g.batch = splits;
+  g.sA = kc; g.sA2 = kc; g.sW = kc; g.sBias = 0; g.sRes = 0;
+  g.sC = (long long)a.M * a.N;
+  g.C = workspace; g.ldc = a.N;
+  g.bias = nullptr; g.res = nullptr; g.act = 0; g.res_mode = 0;
+  const int st = tce_gemm_f32(&g, stream);
+  if (st != TCE_OK) return st;
+  const long long total = (long long)a.M * (a.N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
+                     a.res, a.C, a.M, a.N, splits, a.ldc, a.ldres, a.act, a.res_mode);
+  TCE_CHECK_LAUNCH("tce_gemm_splitk_f32(reduce)");
+  return TCE_OK;
+}

@@ -127,8 +127,9 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         m1 = ar.mark()
         hdn = A(M, ff)
         gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
+        sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
         gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
-                res_mode=RES_ADD)
+                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
         ar.release(m1)
 
     def ln_(x, pre):

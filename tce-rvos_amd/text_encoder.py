@@ -50,17 +50,21 @@ class TextPlan:
                                      sd["embeddings.LayerNorm.weight"].data_ptr(), sd["embeddings.LayerNorm.bias"].data_ptr(),
                                      x.data_ptr(), L, C, self.eps, s), "tce_embed_ln_f32")
         qkv, att, hdn = A(L, 3 * C), A(L, C), A(L, self.ff)
+        # M = L (32 tokens) against 768..3072-deep weights: split K so that ~200 workgroups stream each weight matrix
+        # instead of N/64 (ops.splitk_for); the partial sums meet in `ws`
+        sk_qkv, sk_out, sk_f1, sk_f2 = (ops.splitk_for(L, n, k) for n, k in ((3 * C, C), (C, C), (self.ff, C), (C, self.ff)))
+        ws = A(max(sk_qkv * L * 3 * C, sk_out * L * C, sk_f1 * L * self.ff, sk_f2 * L * C))
         for wqkv, bqkv, p in self.layers:
-            gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv)
+            gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
             check(lib().tce_mha_small64_f32(qkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s), "tce_mha_small64_f32")
             gemm_ex(att, sd[p + "attention.output.dense.weight"], x, L, C, C, C, C, C, bias=sd[p + "attention.output.dense.bias"],
-                    res=x, ldres=C, res_mode=RES_ADD)
+                    res=x, ldres=C, res_mode=RES_ADD, splitk=sk_out, ws=ws)
             ops.layernorm(x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], self.eps,
                           out=x)
             gemm_ex(x, sd[p + "intermediate.dense.weight"], hdn, L, self.ff, C, C, C, self.ff,
-                    bias=sd[p + "intermediate.dense.bias"], act=ACT_GELU)
+                    bias=sd[p + "intermediate.dense.bias"], act=ACT_GELU, splitk=sk_f1, ws=ws)
             gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
-                    bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD)
+                    bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws)
             ops.layernorm(x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], self.eps, out=x)
         pooled = A(C)
         gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])

@@ -436,3 +436,30 @@ def test_conv_with_identity_and_relu_after_residual(ops, stride, k, cin, cout):
     got = out.view(T, Ho, Wo, cout).permute(0, 3, 1, 2).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(32, 768, 3072, 16), (32, 2304, 768, 4), (25, 256, 2048, 8), (1, 768, 768, 2),
+                                          (100, 2152, 512, 4)])
+@pytest.mark.parametrize("act,res_mode", [(0, 0), (2, 0), (0, 1), (3, 1)])
+def test_gemm_splitk(ops, M, N, K, splits, act, res_mode):
+    """Split-K path (skinny deep GEMMs: RoBERTa at 32 tokens, decoder FFNs) == the plain GEMM epilogue semantics."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.linear(a, w, b)
+    if act == 2:
+        ref = F.gelu(ref)
+    if res_mode == 1:
+        ref = ref + r
+    if act == 3:
+        ref = F.relu(ref)
+    out = torch.empty(M, N, device="cuda")
+    ws = torch.empty(splits * M * N, device="cuda")
+    ops.gemm_ex(dev(a), dev(w), out, M, N, K, K, K, N, bias=dev(b), act=act, res=dev(r) if res_mode else None, ldres=N,
+                res_mode=res_mode, splitk=splits, ws=ws)
+    close(out, ref, 1e-4, 2e-4)
+    was, ops.SPLITK_ENABLED = ops.SPLITK_ENABLED, True
+    try:
+        assert ops.splitk_for(32, 768, 3072) == 16 and ops.splitk_for(24100, 256, 2048) == 1 and ops.splitk_for(32, 768, 768) == 4
+    finally:
+        ops.SPLITK_ENABLED = was
