@@ -80,7 +80,7 @@ def main():
             dist.init_process_group("gloo")
 
     from tce_rvos_amd import build_model, ops
-    from tce_rvos_amd.dist import gather_clip_masks
+    from tce_rvos_amd.dist import gather_clip_masks_async
 
     margs = argparse.Namespace(backbone=args.backbone, with_box_refine=True, binary=True, freeze_text_encoder=True,
                                f_token=8, qtrans=True, num_feature_levels=4)
@@ -96,13 +96,13 @@ def main():
     ids[:, :, 0], ids[:, :, -1] = 0, 2
     ids = ids.to(dev)
     targets = [{"size": torch.tensor([H, W])}]
-    gather_buf = None
+    gather_buf, pending = None, None
 
     C = max(1, args.clips_in_flight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(C)] if C > 1 else None
 
     def step(i, gather=True):
-        nonlocal gather_buf
+        nonlocal gather_buf, pending
         if C == 1:
             out = model([clips[i % n_pool]], ids[i % n_pool], targets)
             local = out["pred_masks"]
@@ -117,11 +117,19 @@ def main():
                 cur.wait_stream(streams[c])
             out = outs[0]
             local = torch.cat([o["pred_masks"] for o in outs], 0)
-        if world > 1 and gather:  # the masks of all world*C clips of this step meet on every rank
-            gather_buf = gather_clip_masks(local if args.backend == "nccl" else local.cpu(), world * C)
+        if world > 1 and gather:
+            # the masks of all world*C clips of this step meet on every rank; the collective of step i runs on RCCL's
+            # stream while step i+1 computes, and is completed (stream-ordered) before step i+1's own gather starts
+            if pending is not None:
+                gather_buf = pending.wait()
+            pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C)
         return out
 
     def fence():
+        nonlocal gather_buf, pending
+        if pending is not None:  # the last step's masks must have met inside the timed region
+            gather_buf = pending.wait()
+            pending = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

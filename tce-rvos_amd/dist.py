@@ -46,6 +46,48 @@ def gather_clip_masks(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     return torch.cat([out[r, :counts[r]] for r in range(world)], 0)
 
 
+class PendingGather:
+    """An all-gather of one step's masks in flight on the collective stream; `wait()` returns the gathered tensor.
+    Lets the caller launch the next clip's forward before the previous step's masks have met (the collective moves
+    1.44 MB per clip over xGMI while the matrix cores work on the next clip)."""
+
+    def __init__(self, work, out, counts, keep):
+        self._work, self._out, self._counts, self._keep = work, out, counts, keep
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()  # stream-ordered for RCCL (no host block), blocking for gloo
+            self._work = None
+        out, counts = self._out, self._counts
+        if all(c == out.shape[1] for c in counts):
+            return out.flatten(0, 1)
+        return torch.cat([out[r, :counts[r]] for r in range(len(counts))], 0)
+
+
+def gather_clip_masks_async(local: torch.Tensor, n_total: int, group=None) -> PendingGather:
+    """Non-blocking form of gather_clip_masks for equal or ragged shards (RCCL / gloo)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingGather(None, local[None], [local.shape[0]], None)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    nmax = max(counts)
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} clips, expected {counts[rank]}")
+    padded = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded = torch.cat([local, pad], 0)
+    padded = padded.contiguous()
+    out = torch.empty((world, nmax) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.unbind(0))
+        work = dist.all_gather(parts, padded, group=group, async_op=True)
+    else:
+        work = dist.all_gather_into_tensor(out.view((world * nmax,) + tuple(local.shape[1:])), padded, group=group,
+                                           async_op=True)
+    return PendingGather(work, out, counts, padded)
+
+
 def run_sharded(forward_clip, clips: List, n_total: int = None, group=None) -> torch.Tensor:
     """forward_clip(clip) -> mask tensor [T,Q,h,w]; `clips` is the GLOBAL list (every rank indexes its block)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -21,6 +21,18 @@ def _lin(A, x, M, K, w, b, N, **kw):
     return out
 
 
+# Diagnostic: when set to a list, run_clip appends (stage name, event recorded on the main stream at the END of the
+# stage) -- tools/stage_times.py (eager mode only).
+STAGE_EVENTS = None
+
+
+def _stage(name):
+    if STAGE_EVENTS is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        STAGE_EVENTS.append((name, e))
+
+
 class _Fork:
     """Runs a block of launches on a side stream (inside hipGraph capture this becomes a parallel graph branch);
     without a side stream it degenerates to in-order execution on the current stream."""
@@ -70,9 +82,11 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     Q = cfg.num_queries
     ff = cfg.dim_feedforward
 
+    _stage("start")
     # ------------------------------------------------------------------ backbone
     feats = (_resnet_backbone if cfg.is_resnet else _swin_backbone)(model, frames, ar, sizes)
 
+    _stage("backbone")
     # ------------------------------------------------------------------ text (FeatureResizer :616-635)
     if text_fork is not None:
         text_fork.join()
@@ -89,6 +103,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         v = _lin(A, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
         return k, v
 
+    _stage("text join + resizer")
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
     src = A(T * S, D)  # [T, S, 256]: the encoder sequence
     fk, fv = text_kv("fusion_module.multihead_attn.")
@@ -114,6 +129,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                 sA=hw * D, sC=S * D, sRes=hw * D)
         ar.release(m0)
 
+    _stage("input_proj + fusion")
     # ------------------------------------------------------------------ encoder (:611-627)
     lvl_pos, enc_ref = sc["lvl_pos"], sc["enc_ref"]
     Fk = cfg.f_token
@@ -199,6 +215,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         ln_(src, lp + "norm2")
     memory = src
 
+    _stage("encoder")
     # ------------------------------------------------------------------ decoder (:721-790) + heads (:330-365)
     nl = cfg.dec_layers
     dar = side_arena if side_arena is not None else ar
@@ -272,10 +289,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     with dec_fork:
         hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
 
+    _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
     mask_feats = _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_)
     dec_fork.join()
 
+    _stage("pixel decoder")
     # ------------------------------------------------------------------ dynamic mask head (:371-380, 426-510)
     h4, w4 = sizes[0]
     npar = cfg.num_gen_params
@@ -295,6 +314,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     masks = A(nl, T, Q, h4, w4)
     ops.mask_tail(G, tail, mask_refs, ref_ld, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
 
+    _stage("mask head (+ decoder join)")
     # ------------------------------------------------------------------ output dict (:360-393); leave the arena
     K = cfg.num_classes
     out = {

@@ -32,7 +32,22 @@ def _worker(rank, world, port, n_total, q):
     ok = seen == list(range(lo, hi)) and tuple(out.shape) == (n_total, 2, 3, 4, 5)
     ok = ok and all(torch.equal(out[c], torch.full((2, 3, 4, 5), float(c)) + torch.arange(5, dtype=torch.float32))
                     for c in range(n_total))
-    q.put((rank, ok, len(seen)))
+    # the overlapped form bench.py uses: step i's gather is completed only after step i+1 has been launched
+    from tce_rvos_amd.dist import gather_clip_masks_async
+    pend, got = None, []
+    for step in range(3):
+        local = torch.stack([fake_forward(c) + 100.0 * step for c in range(lo, hi)], 0) if hi > lo else \
+            torch.zeros((0, 2, 3, 4, 5))
+        nxt = gather_clip_masks_async(local, n_total)
+        if pend is not None:
+            got.append(pend.wait())
+        pend = nxt
+    got.append(pend.wait())
+    for step, g in enumerate(got):
+        ok = ok and tuple(g.shape) == (n_total, 2, 3, 4, 5) and all(
+            torch.equal(g[c], torch.full((2, 3, 4, 5), float(c) + 100.0 * step) + torch.arange(5, dtype=torch.float32))
+            for c in range(n_total))
+    q.put((rank, ok, hi - lo))
     dist.barrier()
     dist.destroy_process_group()
 
