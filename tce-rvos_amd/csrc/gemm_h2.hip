@@ -4,17 +4,19 @@
 // Operands arrive as fp16 planes (hi, lo) in HBM -- produced by tce_split_f16_f32 here; in a planned dataflow by the
 // epilogue of whichever kernel produced the tensor -- so a K slice moves HBM/L2 -> LDS with global_load_lds_dwordx4
 // (no VGPR staging, no conversion VALU, no ds_write) into a 3-slot ring, a slice issued two slices before its use,
-// behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per slice placed mid-slice, every fragment read prefetched
-// under the previous half's MFMAs.  The LDS image is lane-linear per DMA instruction (16 rows x 64 B), so the
+// behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per slice.  The LDS image is lane-linear per DMA instruction (16 rows x 64 B), so the
 // bank-conflict-free XOR swizzle is applied on the SOURCE address.  256x128 tile, 8 waves (4x2) of 64x64, BK = 32,
 // 48 KiB per slot.  A may also be stored K-slice-major [K/32][M][32] (a_slice) so every DMA piece is contiguous.
 //
-// Measured (MI355X): bit-identical results; 0-15 % faster than the shipped register-staged kernel whatever the loop
-// structure.  Removing ALL DMA from the loop leaves 85 % of the time, removing the MFMAs 80 %; the bare MFMA loop of
-// tools/mfma_peak.py (same 8 ds_read_b128 per 12 MFMAs, two waves per SIMD, no memory) sustains 1.6-1.7 PFLOP/s
-// chip-wide (clock-limited: 2.0 PFLOP/s-equivalent per CU when only 190 CUs issue), 1.3-1.6 with a barrier per 24
-// MFMAs -- so both kernels already run at 50-55 % of what the matrix pipe can sustain under this mix, and the
-// remaining gap is barrier phases, not the memory path.
+// Measured (MI355X): bit-identical results; 5-15 % faster than the shipped register-staged kernel whatever the loop
+// structure (barrier at the top or mid-slice, fragments prefetched or not, DMA issue interleaved or staggered between
+// the two waves of a SIMD as below).  Ablation of the K loop at 24100x256xK (per 32-deep slice, K 1024 -> 2048):
+//   full 1.36 us = loop skeleton 0.15 + barrier 0.03 + fragment ds_reads 0.23 + DMA 0.48 + MFMA 0.46 -- the parts ADD.
+// The 16 ds_read_b128 per wave (128 KiB per CU and slice) take exactly the LDS array's 256 B/clk; the 48 KiB DMA
+// fill shares that array and runs at ~100 GB/s per CU; the MFMAs (0.64 us of pipe time at 2.4 GHz) hide only partly
+// and pull the clock down for everything else (tools/mfma_peak.py: 1.6-1.7 PFLOP/s sustained chip-wide).  A faster
+// kernel must cut LDS bytes per MFMA (one wave per SIMD with 128x64 wave tiles: -25 % fragment reads; 256x256
+// workgroup tiles: -33 % fill) and hand-interleave the three streams -- DESIGN.md section 3.1 / 8.
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "../../include/tce_rvos.h"
@@ -127,69 +129,33 @@ __global__ void __launch_bounds__(512, 1) gemm_h2_kernel(const H2Args p, const i
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks][j][0], fa[ks][i][0], acc[i][j], 0, 0, 0);
       }
   };
-  // Ring discipline (one barrier per slice, placed MID-slice so that nothing the matrix pipe needs is ever fetched
-  // right after it):
-  //   first-half MFMAs of slice kt            (fragments already in registers)
-  //   s_waitcnt vmcnt(6) ; s_barrier          slice kt+1 has landed for every wave (slice kt+2 may still fly);
-  //                                           every wave also holds BOTH halves of slice kt in registers, so
-  //                                           slot kt%3 is free
-  //   ds_read first half of slice kt+1        lands under the second-half MFMAs
-  //   second-half MFMAs of slice kt, the 6 DMA pieces of slice kt+3 (-> slot kt%3) interleaved between them
-  //   ds_read second half of slice kt+1       lands under the first-half MFMAs of slice kt+1
-  // A slice is issued two full slices before it is needed (96 KiB per CU in flight).
+  // Ring discipline: at the top of slice kt this wave's DMAs of slice kt have landed (counted vmcnt leaves the 6 of
+  // slice kt+1 in flight), the barrier publishes every wave's share and proves slot (kt+2)%3 -- slice kt-1 -- is no
+  // longer read.  A wave's instruction stream is in-order, so its own DMA issue (~90 cycles per piece here) and its
+  // MFMAs serialise; the overlap has to come from the OTHER wave of the SIMD.  Waves w and w+4 share a SIMD (cyclic
+  // SIMD assignment), so waves 0-3 issue slice kt+2's DMA pieces BEFORE their MFMAs and waves 4-7 AFTER theirs:
+  // while one of the pair feeds the memory pipe the other feeds the matrix pipe.
   long long* const stamps = (g_h2_stamps && blockIdx.x < 256) ? g_h2_stamps + (blockIdx.x * 8 + wave) * 8 : nullptr;
   long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_begin = 0;
   if (stamps) t_begin = (long long)__builtin_amdgcn_s_memtime();
+  const bool early = __builtin_amdgcn_readfirstlane(wave < 4);
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  if (nk > 2) issue(2, 2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  read_half(smem, 0);
-  read_half(smem, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    long long t0 = 0, t1 = 0, t2 = 0;
+    const unsigned char* st = smem + (kt % NSTAGE) * STAGE;
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (early && kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(st, 0);
+    read_half(st, 1);
     mfma_half(0);
+    mfma_half(1);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (stamps) t0 = (long long)__builtin_amdgcn_s_memtime();
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (stamps) t1 = (long long)__builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamps) t2 = (long long)__builtin_amdgcn_s_memtime();
-      read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 0);
-    }
-    // second half: 12 MFMAs with the DMA pieces of slice kt+3 dropped between them
-    const bool more = kt + 3 < nk;
-    const int nslot = kt % NSTAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][1], fa[1][i][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][0], fa[1][i][1], acc[i][j], 0, 0, 0);
-        if (more) {
-          __builtin_amdgcn_sched_barrier(0);
-          issue_one(kt + 3, nslot, 2 * i + j);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j][0], fa[1][i][0], acc[i][j], 0, 0, 0);
-      }
-    if (more) {
-      __builtin_amdgcn_sched_barrier(0);
-      issue_one(kt + 3, nslot, 4);
-      issue_one(kt + 3, nslot, 5);
-    }
+    if (!early && kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) read_half(smem + ((kt + 1) % NSTAGE) * STAGE, 1);
-    if (stamps) {
-      t_wait += t1 - t0; t_bar += t2 - t1;
-    }
   }
   if (stamps && lane == 0) {
     stamps[0] = t_wait; stamps[1] = t_bar; stamps[2] = t_issue; stamps[3] = t_comp;
