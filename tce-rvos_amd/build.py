@@ -2,9 +2,12 @@
 
     python -m tce_rvos_amd.build        (or __graft_entry__.build())
 
-hipcc cross-compiles without a GPU.  Objects are cached by source mtime under csrc/_obj/.
+hipcc cross-compiles without a GPU.  Objects are cached by source mtime under csrc/_obj/; translation units are
+compiled in parallel (TCE_BUILD_JOBS, default = CPU count capped at 8).
 """
+import glob
 import os
+from concurrent.futures import ThreadPoolExecutor
 import subprocess
 import sys
 
@@ -13,7 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm_f16x3.hip", "gemm_h2.hip", "norm.hip", "attn.hip", "msda.hip", "misc.hip", "text.hip", "resnet.hip", "frontend.hip"]
+# slowest first (they gate the parallel build): the GEMM translation units carry one epilogue body per (act, res) combination
+SOURCES = ["gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "gemm_h2.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
+           "text.hip", "resnet.hip", "frontend.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -28,17 +33,23 @@ def _newer(src_list, target):
 def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "tce_rvos.h")]
-    objs = []
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "tce_rvos.h")]
+    objs, todo = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         if force or _newer([src] + headers, obj):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            todo.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
         objs.append(obj)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = int(os.environ.get("TCE_BUILD_JOBS", min(8, os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+        list(pool.map(run, todo))
     if force or _newer(objs, LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -191,9 +191,8 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int tce_gemm_f16x3_launch(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3.hip
-bool tce_gemm_f16x3_pc_launch(const tceGemmArgs& a, hipStream_t s);        // gemm_f16x3.hip
-extern int g_pc_ablate;
+int tce_gemm_f16x3_launch_big(const tceGemmArgs& a, int tile, hipStream_t s);    // gemm_f16x3_big.hip
+int tce_gemm_f16x3_launch_small(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3_small.hip
 
 static int g_gemm_mode = 1;  // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate)
 
@@ -208,14 +207,8 @@ extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
 static int g_force_tile = 0;
 extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile (tuning aid)
-  if (tile == 1001 || tile == 1002) {  // ablation builds of the producer/consumer kernel (timing only, wrong results)
-    g_pc_ablate = tile - 1000;
-    g_force_tile = 1;
-    return TCE_OK;
-  }
-  g_pc_ablate = 0;
-  TCE_CHECK_ARG(tile == 0 || tile == 1 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465 || tile == 256129 || tile == 256130 || tile == 12865,
-                "tce_gemm_force_tile: bad tile (1 = persistent producer/consumer kernel where applicable)");
+  TCE_CHECK_ARG(tile == 0 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465,
+                "tce_gemm_force_tile: bad tile (0, 256128, 128128, 12864, 6464 or 6465)");
   g_force_tile = tile;
   return TCE_OK;
 }
@@ -246,6 +239,33 @@ extern "C" int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t 
   return select_tile_ex(M, N, K, batch, conv);
 }
 
+namespace {
+__global__ void __launch_bounds__(256) epi_fix_kernel(float* __restrict__ C, const float* __restrict__ res, const int M,
+                                                      const int N, const long long ldc, const long long ldres,
+                                                      const long long sC, const long long sRes, const int res_mode,
+                                                      const int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float* c = C + (long long)blockIdx.y * sC + (long long)m * ldc + n;
+  float v = *c;
+  if (res_mode) {
+    const float r = res[(long long)blockIdx.y * sRes + (long long)m * ldres + n];
+    v = res_mode == 1 ? v + r : v * r;
+  }
+  if (relu) v = fmaxf(v, 0.f);
+  *c = v;
+}
+}  // namespace
+
+static int launch_epi_fix(const tceGemmArgs& a, int res_mode, bool relu, hipStream_t s) {
+  const long long total = (long long)a.M * a.N;
+  hipLaunchKernelGGL(epi_fix_kernel, dim3(tce_cdiv(total, 256), a.batch > 0 ? a.batch : 1), dim3(256), 0, s, a.C, a.res, a.M, a.N,
+                     (long long)a.ldc, (long long)a.ldres, (long long)a.sC, (long long)a.sRes, res_mode, relu ? 1 : 0);
+  TCE_CHECK_LAUNCH("tce_gemm_f32(epilogue fix-up)");
+  return TCE_OK;
+}
+
 extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   TCE_CHECK_ARG(args != nullptr, "tce_gemm_f32: null args");
   tceGemmArgs a = *args;
@@ -271,19 +291,33 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
     TCE_CHECK_ARG(!a.A2 || (a.lda2 % 4 == 0 && a.lda2 >= a.K), "tce_gemm_f32: lda2 invalid");
   }
   hipStream_t s = (hipStream_t)stream;
+  // epilogue combinations without a specialised kernel body (gemm_epilogue.h) = GEMM with the activation only, then one
+  // elementwise pass for the residual (and a trailing ReLU for act 3)
+  bool fix = false, fix_relu = false;
+  int fix_res_mode = 0;
+  if (a.act == 3 && a.res_mode == 0) a.act = 1;
+  if (!tce_epi_supported(a.act, a.res_mode)) {
+    TCE_CHECK_ARG(a.res != a.C, "tce_gemm_f32: act=%d with res_mode=%d has no fused epilogue; it cannot run in place", a.act,
+                  a.res_mode);
+    fix = true;
+    fix_res_mode = a.res_mode;
+    fix_relu = a.act == 3;
+    if (a.act == 3) a.act = 0;
+    a.res_mode = 0;
+  }
   const int tile = select_tile_ex(a.M, a.N, a.K, a.batch, a.conv);
   if (g_gemm_mode == 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
-    // large problems: persistent producer/consumer kernel; small ones: the symmetric tiles
-    if (g_force_tile != 1 || !tce_gemm_f16x3_pc_launch(a, s)) tce_gemm_f16x3_launch(a, tile == 1 ? 12864 : tile, s);
+    if (tile == 256128 || tile == 128128) tce_gemm_f16x3_launch_big(a, tile, s);
+    else tce_gemm_f16x3_launch_small(a, tile, s);
     TCE_CHECK_LAUNCH("tce_gemm_f32(f16x3)");
-    return TCE_OK;
+    return fix ? launch_epi_fix(a, fix_res_mode, fix_relu, s) : TCE_OK;
   }
   if (tile == 128128 || tile == 256128) launch<128, 128>(a, s);
   else if (tile == 6465) launch<64, 64>(a, s);
   else if (tile == 12864) launch<128, 64>(a, s);
   else launch<64, 64>(a, s);
   TCE_CHECK_LAUNCH("tce_gemm_f32");
-  return TCE_OK;
+  return fix ? launch_epi_fix(a, fix_res_mode, fix_relu, s) : TCE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -161,7 +161,10 @@ __device__ __forceinline__ bool tce_epi_vec_ok(const float* C, long long ldc, co
   return ok;
 }
 
-// runs BODY(ACT, RES) with compile-time constants chosen from the run-time (act, res_mode)
+// runs BODY(ACT, RES) with compile-time constants chosen from the run-time (act, res_mode).  Only the combinations the
+// path uses are specialised (every one is another inlined copy of the epilogue in every GEMM kernel, and compile time
+// is proportional): none, +res, *res, ReLU, ReLU then +res, GELU, ReLU after +res.  The host (tce_gemm_f32) folds
+// every other legal combination onto these plus one elementwise pass (tce_epi_supported / epi_fix_kernel, gemm.hip).
 #define TCE_EPI_DISPATCH(act, res_mode, BODY) \
   switch ((act) * 3 + (res_mode)) {           \
     case 0: BODY(0, 0); break;                \
@@ -169,11 +172,11 @@ __device__ __forceinline__ bool tce_epi_vec_ok(const float* C, long long ldc, co
     case 2: BODY(0, 2); break;                \
     case 3: BODY(1, 0); break;                \
     case 4: BODY(1, 1); break;                \
-    case 5: BODY(1, 2); break;                \
     case 6: BODY(2, 0); break;                \
-    case 7: BODY(2, 1); break;                \
-    case 8: BODY(2, 2); break;                \
-    case 9: BODY(3, 0); break;                \
-    case 10: BODY(3, 1); break;               \
-    default: BODY(3, 2); break;               \
+    default: BODY(3, 1); break;               \
   }
+
+static inline bool tce_epi_supported(int act, int res_mode) {
+  const int c = act * 3 + res_mode;
+  return c == 0 || c == 1 || c == 2 || c == 3 || c == 4 || c == 6 || c == 10;
+}

@@ -463,3 +463,26 @@ def test_gemm_splitk(ops, M, N, K, splits, act, res_mode):
         assert ops.splitk_for(32, 768, 3072) == 16 and ops.splitk_for(24100, 256, 2048) == 1 and ops.splitk_for(32, 768, 768) == 4
     finally:
         ops.SPLITK_ENABLED = was
+
+
+@pytest.mark.parametrize("act,res_mode", [(1, 2), (2, 1), (2, 2), (3, 0), (3, 2), (1, 1)])
+def test_gemm_unspecialised_epilogue_combinations(ops, act, res_mode):
+    """Epilogue combinations without a specialised kernel body run as GEMM + one elementwise pass: same semantics
+    (activation, then residual, act 3 = ReLU after the residual)."""
+    g = torch.Generator().manual_seed(act * 3 + res_mode)
+    M, N, K = 300, 200, 96
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.linear(a, w, b)
+    if act == 1:
+        ref = F.relu(ref)
+    if act == 2:
+        ref = F.gelu(ref)
+    if res_mode == 1:
+        ref = ref + r
+    if res_mode == 2:
+        ref = ref * r
+    if act == 3:
+        ref = F.relu(ref)
+    out = ops.gemm(dev(a), dev(w), bias=dev(b), act=act, res=dev(r) if res_mode else None, res_mode=res_mode)
+    close(out, ref, 1e-4, 2e-4)

@@ -58,7 +58,7 @@ def time_tile(g, tile, reps=20):
     lib().tce_gemm_force_tile(0)
     return e0.elapsed_time(e1) * 1e-3 / (2 * reps)
 
-TILES = [256128, 128128, 12864, 12865, 6464, 6465]
+TILES = [256128, 128128, 12864, 6464, 6465]
 tot_auto = tot_best = 0.0
 rows = []
 for k, gs in groups.items():
