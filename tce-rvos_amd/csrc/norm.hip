@@ -178,6 +178,102 @@ __global__ void __launch_bounds__(256) patch_embed_kernel(const float* __restric
   }
 }
 
+// Lane-per-token form (C % 8 == 0, C <= 152; TOK tokens x (C+4) floats of LDS): a lane gathers its
+// token's 48 taps with 16-byte loads (lanes = consecutive patches of a row -> coalesced), the weights are wave-uniform
+// (scalar loads), the raw conv outputs go to an LDS row per token, LayerNorm statistics are a serial pass over the
+// lane's own row (no cross-lane traffic), and the normalised tile -- TOK tokens x C floats, contiguous in the
+// token-major output -- is written cooperatively as a float4 stream.
+template <int CO_CHUNK, int TOK>
+__global__ void __launch_bounds__(TOK) patch_embed_lane_kernel(const float* __restrict__ frames,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ out,
+                                                               const int H, const int W, const int C, const float eps,
+                                                               const long long ntok, const int Hp, const int Wp) {
+  extern __shared__ float sm[];
+  const int pitch = C + 4;
+  float* raw = sm;                      // [TOK][pitch]
+  float* smean = sm + TOK * pitch;      // [TOK]
+  float* srstd = smean + TOK;           // [TOK]
+  const int tid = threadIdx.x;
+  const long long tok0 = (long long)blockIdx.x * TOK;
+  const long long tok = tok0 + tid;
+  float tap[48];
+  if (tok < ntok) {
+    const int t = (int)(tok / (Hp * Wp));
+    const int rem = (int)(tok - (long long)t * Hp * Wp);
+    const int py = rem / Wp, px = rem - py * Wp;
+    const bool vec = ((W & 3) == 0) && (px * 4 + 3 < W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const int yy = py * 4 + ky;
+        const float* row = frames + (((long long)t * 3 + c) * H + min(yy, H - 1)) * W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy < H) {
+          if (vec) {
+            v = *reinterpret_cast<const f32x4*>(row + px * 4);
+          } else {
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+              if (px * 4 + kx < W) v[kx] = row[px * 4 + kx];
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) tap[c * 16 + ky * 4 + kx] = v[kx];
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 48; ++k) tap[k] = 0.f;
+  }
+  float* myrow = raw + tid * pitch;
+  float s = 0.f;
+  for (int co = 0; co < C; co += CO_CHUNK) {  // weights are wave-uniform: the compiler keeps them in SGPRs
+    float acc[CO_CHUNK];
+#pragma unroll
+    for (int j = 0; j < CO_CHUNK; ++j) acc[j] = b[co + j];
+#pragma unroll
+    for (int j = 0; j < CO_CHUNK; ++j) {
+      const float* wr = w + (long long)(co + j) * 48;
+#pragma unroll
+      for (int k = 0; k < 48; ++k) acc[j] = fmaf(tap[k], wr[k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CO_CHUNK; j += 4) {
+      f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+      *reinterpret_cast<f32x4*>(myrow + co + j) = v;
+      s += (acc[j] + acc[j + 1]) + (acc[j + 2] + acc[j + 3]);
+    }
+  }
+  const float mean = s / (float)C;
+  float q = 0.f;
+  for (int c = 0; c < C; c += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(myrow + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[e] - mean;
+      q = fmaf(d, d, q);
+    }
+  }
+  smean[tid] = mean;
+  srstd[tid] = rsqrtf(q / (float)C + eps);
+  __syncthreads();
+  const int c4n = C >> 2;
+  const long long nvalid = min((long long)TOK, ntok - tok0);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + tok0 * C);
+  for (long long i = tid; i < nvalid * c4n; i += TOK) {
+    const int r = (int)(i / c4n), c4 = (int)(i - (long long)r * c4n);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(raw + r * pitch + c4 * 4);
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(gamma)[c4], b4 = reinterpret_cast<const f32x4*>(beta)[c4];
+    const float m = smean[r], rs = srstd[r];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - m) * rs * g4[e] + b4[e];
+    o4[i] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm on channels-last [T, HW, C]: each (frame, group) is split over `nsplit` workgroups that
 // compute (count, mean, M2) of their row range (two passes over the chunk, second one from L2); the apply
@@ -307,6 +403,24 @@ extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const fl
   TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && C > 0 && C <= 256, "tce_patch_embed_f32: need 0 < C <= 256 (C=%d)", C);
   const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
   const long long ntok = (long long)T * Hp * Wp;
+  if (C % 8 == 0 && C <= 152 && tce_aligned16(frames) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta)) {
+    constexpr int TOK = 128;  // tokens (= threads) per workgroup: 52 KiB of LDS at C = 96 -> three workgroups per CU
+    const size_t lds = (size_t)(TOK * (C + 4) + 2 * TOK) * sizeof(float);
+    static size_t lds_allowed = 64 * 1024;  // dynamic LDS above 64 KiB has to be requested once per function
+    if (lds > lds_allowed) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_embed_lane_kernel<8, TOK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        tce_set_error("tce_patch_embed_f32: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        return TCE_ELAUNCH;
+      }
+      lds_allowed = 160 * 1024;
+    }
+    hipLaunchKernelGGL((patch_embed_lane_kernel<8, TOK>), dim3(tce_cdiv(ntok, TOK)), dim3(TOK), lds, (hipStream_t)stream, frames, w, b,
+                       gamma, beta, out, H, W, C, eps, ntok, Hp, Wp);
+    TCE_CHECK_LAUNCH("tce_patch_embed_f32");
+    return TCE_OK;
+  }
   const int tpb = 64;
   const size_t smem = (size_t)(48 * C + 4 * 48) * sizeof(float);
   hipLaunchKernelGGL((patch_embed_kernel<4>), dim3(tce_cdiv(ntok, tpb)), dim3(256), smem, (hipStream_t)stream, frames, w,

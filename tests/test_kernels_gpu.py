@@ -144,7 +144,8 @@ def test_groupnorm(ops, T, HW, C, G, relu):
     close(out.view(T, HW, C).permute(0, 2, 1).reshape(T, C, HW, 1), ref, 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("T,H,W,C", [(2, 72, 100, 96), (1, 30, 41, 128), (1, 8, 8, 32)])
+@pytest.mark.parametrize("T,H,W,C", [(2, 72, 100, 96), (1, 30, 41, 128), (1, 8, 8, 32), (5, 360, 640, 96), (1, 37, 50, 192),
+                                     (2, 33, 64, 152)])
 def test_patch_embed(ops, T, H, W, C):
     g = torch.Generator().manual_seed(H)
     x = torch.randn(T, 3, H, W, generator=g)
