@@ -362,11 +362,11 @@ class ReferFormer(nn.Module):
 
     def _tokenise(self, captions, device):
         if isinstance(captions, (list, tuple)):
-            ids, att = self.tokenizer(list(captions))
-        else:
+            ids, att = self.tokenizer(list(captions))  # host tensors
+            if bool((att != 1).any()):
+                raise NotImplementedError("padded captions (B > 1) are not supported")
+        else:  # token ids: every position is a token (no device read-back here: it would serialise consecutive clips)
             ids, att = captions, torch.ones_like(captions)
-        if bool((att != 1).any()):
-            raise NotImplementedError("padded captions (B > 1) are not supported")
         return ids.to(device), att.to(device)
 
     def _text_plan(self):
