@@ -123,6 +123,99 @@ __global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ val
   if (active) out[item * D + d] = acc;
 }
 
+// Fused kernel, 16-byte form: EIGHT lanes per (frame, query, head) item, a lane owns 4 of the 32 channels, so one
+// wave instruction fetches eight 128-byte rows (the dword-per-lane form above is bound by the number of gather
+// instructions: 6.2 M wave-instructions of 16 address-cycles each at config 2).  Lane i of an item holds sampling
+// points i and i+8, which keeps the softmax reduction tree of the dword form (xor 8, 4, 2, 1) -- results are
+// bit-identical.  Same head <-> XCD placement.
+__global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restrict__ value, const float* __restrict__ proj,
+                                                            const float* __restrict__ ref, float* __restrict__ out,
+                                                            LevelInfo lv, int N, int S, int M, int Lq, int L, int P,
+                                                            int ref_dim, int ref_per_frame, long long total) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;                  // channel quad / point pair index inside the item
+  const int gbase = lane & ~7;               // first lane of this item's 8-lane group
+  long long item;
+  if (M == 8) {
+    const long long pair = (long long)(blockIdx.x >> 3) * 32 + (threadIdx.x >> 3);  // n*Lq + q
+    item = pair * 8 + (blockIdx.x & 7);
+    if (pair >= total / 8) item = total;
+  } else {
+    item = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);  // (n*Lq + q)*M + m
+  }
+  const bool active = item < total;
+  const int LP = L * P;
+  int m = 0, q = 0, n = 0;
+  if (active) {
+    long long r = item;
+    m = (int)(r % M); r /= M;
+    q = (int)(r % Lq);
+    n = (int)(r / Lq);
+  }
+  float px[2] = {0.f, 0.f}, py[2] = {0.f, 0.f}, pw[2] = {-3.0e38f, -3.0e38f};
+  bool have[2] = {false, false};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pj = sub + 8 * e;
+    if (active && pj < LP) {
+      have[e] = true;
+      const int l = pj / P;
+      const int ncol = M * LP * 3;
+      const float* row = proj + ((long long)n * Lq + q) * ncol;
+      const float ox = row[(m * LP + pj) * 2 + 0];
+      const float oy = row[(m * LP + pj) * 2 + 1];
+      pw[e] = row[M * LP * 2 + m * LP + pj];  // logit
+      const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+      if (ref_dim == 2) {
+        px[e] = rp[0] + ox / (float)lv.W[l];
+        py[e] = rp[1] + oy / (float)lv.H[l];
+      } else {
+        px[e] = rp[0] + ox / (float)P * rp[2] * 0.5f;
+        py[e] = rp[1] + oy / (float)P * rp[3] * 0.5f;
+      }
+    }
+  }
+  // softmax over the LP logits: (point i, point i+8) in-lane = the xor-8 step, then xor 4, 2, 1 across the 8 lanes
+  float mx = fmaxf(pw[0], pw[1]);
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float e0 = have[0] ? __expf(pw[0] - mx) : 0.f, e1 = have[1] ? __expf(pw[1] - mx) : 0.f;
+  float sum = e0 + e1;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float w0 = e0 / sum, w1 = e1 / sum;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const long long row_stride = (long long)M * D;
+  const float* vn = value + ((long long)n * S) * row_stride + m * D + sub * 4;
+  for (int j = 0; j < LP; ++j) {
+    const int src = gbase + (j & 7);
+    const bool hi = j >= 8;  // loop-uniform
+    const float x = __shfl(hi ? px[1] : px[0], src, 64), y = __shfl(hi ? py[1] : py[0], src, 64);
+    const float w = __shfl(hi ? w1 : w0, src, 64);
+    const int l = j / P;
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+    if (active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+      const float* vbase = vn + (long long)lv.start[l] * row_stride;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
+      if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
+      if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
+      if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
+      if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+      const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += w * (c1 * v1[c] + c2 * v2[c] + c3 * v3[c] + c4 * v4[c]);
+    }
+  }
+  if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
+}
+
 // variant of the plain kernel that reads level geometry from device memory (the reference op passes
 // spatial_shapes / level_start_index as device int64 tensors)
 __global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __restrict__ value,
@@ -205,6 +298,13 @@ extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const f
   }
   TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
   const long long total = (long long)N * Lq * M;
+  if (tce_aligned16(value) && tce_aligned16(out)) {  // 16-byte form: 32 items per workgroup
+    const int nb = (M == 8) ? tce_cdiv((long long)N * Lq, 32) * 8 : tce_cdiv(total, 32);
+    hipLaunchKernelGGL(msda_fused_q4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out, lv, N, S, M,
+                       Lq, L, P, ref_dim, ref_per_frame, total);
+    TCE_CHECK_LAUNCH("tce_msda_fused_f32");
+    return TCE_OK;
+  }
   // M == 8: 8 workgroups (one per head / XCD) per group of 8 (frame, query) pairs
   const int nblocks = (M == 8) ? tce_cdiv((long long)N * Lq, 8) * 8 : tce_cdiv(total, 8);
   hipLaunchKernelGGL((msda_kernel<true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, proj, ref,
