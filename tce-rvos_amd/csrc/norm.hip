@@ -49,6 +49,41 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// Narrow rows (C <= 128: Swin stage 1): one HALF-wave per row, the row lives in one float4 per lane (read once),
+// statistics by xor-shuffles inside the 32 lanes.  The full-wave form above leaves 40 of 64 lanes idle at C = 96.
+__global__ void __launch_bounds__(256) layernorm_narrow_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ out,
+                                                               long long M, int C, float eps) {
+  const int lane = threadIdx.x & 63, sub = lane & 31;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int n4 = C >> 2;
+  const bool on = row < M && sub < n4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    v = reinterpret_cast<const f32x4*>(x + row * C)[sub];
+    if (r) v += reinterpret_cast<const f32x4*>(r + row * C)[sub];
+  }
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
+  float q = on ? (a * a + b * b) + (c * c + d * d) : 0.f;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  if (on) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[sub], bb = reinterpret_cast<const f32x4*>(beta)[sub];
+    f32x4 o;
+    o[0] = a * rstd * g[0] + bb[0];
+    o[1] = b * rstd * g[1] + bb[1];
+    o[2] = c * rstd * g[2] + bb[2];
+    o[3] = d * rstd * g[3] + bb[3];
+    reinterpret_cast<f32x4*>(out + row * C)[sub] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // PatchMerging front half: virtual row = concat of 4 neighbours (zero outside), LayerNorm(4C).
 // ---------------------------------------------------------------------------------------------------
@@ -377,7 +412,11 @@ extern "C" int tce_layernorm_f32(const float* x, const float* r, const float* ga
   TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta) &&
                     (!r || tce_aligned16(r)),
                 "tce_layernorm_f32: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(layernorm_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, out,
+  if (C <= 128)
+    hipLaunchKernelGGL(layernorm_narrow_kernel, dim3(tce_cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta,
+                       out, (long long)M, C, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, out,
                      (long long)M, C, eps);
   TCE_CHECK_LAUNCH("tce_layernorm_f32");
   return TCE_OK;
