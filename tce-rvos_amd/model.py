@@ -388,7 +388,7 @@ class ReferFormer(nn.Module):
         if res is None:  # eager: shared arena, single stream
             return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device))
         arena, side_arena, side_stream = res
-        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream)
+        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False)
 
     def _capture(self, key, statics, fn, like):
         """Captures fn((arena, side_arena, side_stream)) into a graph; the arenas belong to the graph (their

@@ -59,11 +59,13 @@ class _Fork:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
-def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None):
+def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
-    beside the pixel decoder's large kernels; it needs its own arena because both branches allocate."""
+    beside the pixel decoder's large kernels; it needs its own arena because both branches allocate.
+    clone_outputs=False returns views into the arenas (valid until the arenas are used again): the graph path owns its
+    arenas and copies the outputs out once per replay, so a second copy inside the graph would be wasted."""
     cfg, w = model.cfg, model._packed
     dev = frames.device
     T, _, H0, W0 = frames.shape
@@ -317,18 +319,19 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     _stage("mask head (+ decoder join)")
     # ------------------------------------------------------------------ output dict (:360-393); leave the arena
     K = cfg.num_classes
+    keep = (lambda t: t.clone()) if clone_outputs else (lambda t: t)
     out = {
-        "pred_logits": logits[-1].reshape(1, T, Q, K).clone(),
-        "pred_boxes": boxes[-1].reshape(1, T, Q, 4).clone(),
-        "pred_masks": masks[-1].reshape(1, T, Q, h4, w4).clone(),
+        "pred_logits": keep(logits[-1].reshape(1, T, Q, K)),
+        "pred_boxes": keep(boxes[-1].reshape(1, T, Q, 4)),
+        "pred_masks": keep(masks[-1].reshape(1, T, Q, h4, w4)),
     }
     if cfg.aux_loss:
-        out["aux_outputs"] = [{"pred_logits": logits[i].reshape(1, T, Q, K).clone(),
-                               "pred_boxes": boxes[i].reshape(1, T, Q, 4).clone(),
-                               "pred_masks": masks[i].reshape(1, T, Q, h4, w4).clone()} for i in range(nl - 1)]
+        out["aux_outputs"] = [{"pred_logits": keep(logits[i].reshape(1, T, Q, K)),
+                               "pred_boxes": keep(boxes[i].reshape(1, T, Q, 4)),
+                               "pred_masks": keep(masks[i].reshape(1, T, Q, h4, w4))} for i in range(nl - 1)]
     if not model.training:
-        out["reference_points"] = mask_refs[-2].reshape(1, T, Q, ref_ld)[..., :2].clone()
-    out["memory"] = memory.reshape(T, S, D).clone()
+        out["reference_points"] = keep(mask_refs[-2].reshape(1, T, Q, ref_ld)[..., :2])
+    out["memory"] = keep(memory.reshape(T, S, D))
     ar.release(m0)
     return out
 
