@@ -52,8 +52,8 @@ typedef struct {
 } tceGemmArgs;
 int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
 /* Same product for skinny, deep problems (M of a few dozen rows, K in the thousands): K is cut into `splits` chunks that
- * run as one batched launch into workspace[splits*M*N], then one pass sums them and applies bias/act/res.  Plain,
- * un-batched GEMMs only; K % (splits*32) == 0, N % 4 == 0. */
+ * run as one batched launch into workspace[splits*M*N], then one pass sums them and applies bias/act/res.  Un-batched
+ * GEMMs and (split-fp16 mode) implicit-GEMM convolutions; K % (splits*32) == 0, N % 4 == 0. */
 int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspace, tceStream stream);
 /* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);

@@ -282,7 +282,9 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
   if (a.conv) {
     TCE_CHECK_ARG(a.A2 == nullptr, "tce_gemm_f32: A2 is not supported with conv");
     TCE_CHECK_ARG(a.Cin % BK == 0, "tce_gemm_f32: conv Cin=%d must be a multiple of %d", a.Cin, BK);
-    TCE_CHECK_ARG(a.K == a.kh * a.kw * a.Cin, "tce_gemm_f32: conv K=%d != kh*kw*Cin", a.K);
+    // batch > 1 with conv = split-K chunks of one convolution (only issued by tce_gemm_splitk_f32, split-fp16 mode)
+    TCE_CHECK_ARG((long long)a.K * a.batch == (long long)a.kh * a.kw * a.Cin, "tce_gemm_f32: conv K=%d x batch != kh*kw*Cin", a.K);
+    TCE_CHECK_ARG(a.batch == 1 || g_gemm_mode == 1, "tce_gemm_f32: split convolutions need the split-fp16 mode");
     TCE_CHECK_ARG(a.M == a.T * a.Ho * a.Wo, "tce_gemm_f32: conv M=%d != T*Ho*Wo", a.M);
     TCE_CHECK_ARG(a.Ho == (a.H + 2 * a.pad - a.kh) / a.stride + 1 && a.Wo == (a.Wd + 2 * a.pad - a.kw) / a.stride + 1,
                   "tce_gemm_f32: conv output size mismatch");
@@ -321,8 +323,8 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split-K for skinny, deep problems (M <= a tile or two, K in the thousands: the RoBERTa projections at 32 tokens,
-// the decoder FFNs on 25 rows): a plain launch has N/64 workgroups streaming the whole K extent of the weights one
+// Split-K for skinny, deep problems (M <= a tile or two, K in the thousands: the level-3 3x3/s2 convolution of C5 with
+// 300 output rows and K = 6912, the RoBERTa projections at 32 tokens, the decoder FFNs on 25 rows): a plain launch has N/64 workgroups streaming the whole K extent of the weights one
 // after the other (9.4 MB at ~0.2 TB/s for 32x768x3072).  The K extent is cut into `splits` chunks that run as the
 // batch dimension of the same kernel into workspace[splits][M][N]; a second kernel sums the partials and applies the
 // epilogue (bias, activation, residual) exactly as the GEMM epilogue would.
@@ -356,7 +358,8 @@ extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, floa
   TCE_CHECK_ARG(args != nullptr && workspace != nullptr, "tce_gemm_splitk_f32: null args/workspace");
   tceGemmArgs a = *args;
   TCE_CHECK_ARG(splits >= 1 && splits <= 64, "tce_gemm_splitk_f32: splits=%d out of range", splits);
-  TCE_CHECK_ARG(!a.conv && a.batch <= 1, "tce_gemm_splitk_f32: plain un-batched GEMMs only");
+  TCE_CHECK_ARG(a.batch <= 1, "tce_gemm_splitk_f32: un-batched problems only");
+  if (a.conv && (g_gemm_mode != 1 || a.Cin % 32 != 0)) splits = 1;  // the exact-fp32 kernel has no split convolution
   TCE_CHECK_ARG(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.K > 0 && a.K % (splits * BK) == 0,
                 "tce_gemm_splitk_f32: N=%d must be a multiple of 4 and K=%d a multiple of splits*%d", a.N, a.K, BK);
   TCE_CHECK_ARG(a.C && tce_aligned16(workspace), "tce_gemm_splitk_f32: null C / unaligned workspace");
@@ -366,7 +369,7 @@ extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, floa
   const int kc = a.K / splits;
   g.K = kc;
   g.batch = splits;
-  g.sA = kc; g.sA2 = kc; g.sW = kc; g.sBias = 0; g.sRes = 0;
+  g.sA = a.conv ? 0 : kc; g.sA2 = kc; g.sW = kc; g.sBias = 0; g.sRes = 0;
   g.sC = (long long)a.M * a.N;
   g.C = workspace; g.ldc = a.N;
   g.bias = nullptr; g.res = nullptr; g.act = 0; g.res_mode = 0;

@@ -140,8 +140,11 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
     unsigned mk = rowmask;
     int ky = 0, kx = 0, c0 = k0;
     if (CONV) {
-      const int tap = (kt * BK) / p.Cin;
-      c0 = k0 - tap * p.Cin;
+      // a batched convolution launch is a split-K launch (tce_gemm_splitk_f32): batch index = K chunk, so the tap /
+      // channel of a slice come from its GLOBAL slice number; A is not offset, W and C are (sW, sC)
+      const int ktg = kt + bz * nk;
+      const int tap = (ktg * BK) / p.Cin;
+      c0 = ktg * BK + kq * 4 - tap * p.Cin;
       ky = tap / p.kw;
       kx = tap - ky * p.kw;
     }

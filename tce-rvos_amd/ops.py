@@ -155,7 +155,7 @@ def gemm_batched(a, w, out, bias=None, act=ACT_NONE):
 
 
 def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT_NONE, out=None, alloc=None, res=None,
-              res_mode=RES_NONE):
+              res_mode=RES_NONE, splitk=1, ws=None):
     """Channels-last convolution as implicit GEMM.  x [T*H*W, Cin]; w_packed [N, kh*kw*Cin] with
     k = (ky*kw+kx)*Cin + c.  Returns [T*Ho*Wo, N]."""
     _chk(x, "x")
@@ -178,7 +178,7 @@ def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT
     g.act, g.res_mode, g.batch, g.conv = act, res_mode, 1, 1
     g.T, g.H, g.Wd, g.Cin, g.Ho, g.Wo = T, H, W, Cin, Ho, Wo
     g.kh, g.kw, g.stride, g.pad = kh, kw, stride, pad
-    _gemm_launch(g)
+    _gemm_launch(g, splitk, ws)
     return out, Ho, Wo
 
 

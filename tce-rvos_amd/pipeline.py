@@ -118,8 +118,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             s = _lin(A, feats[1 + l], T * hw, chs[1 + l], w[f"input_proj.{l}.0.weight"], w[f"input_proj.{l}.0.bias"], D)
         else:
             h5, w5 = sizes[3]
+            # 300 output rows against K = 9*C5 (6912): 20 workgroups would walk the whole K extent one after the other
+            k5 = 9 * chs[3]
+            sk = next((c for c in (8, 6, 4, 3, 2) if k5 % (c * 32) == 0), 1) if T * h * ww <= 2048 else 1
             s, ho, wo = ops.conv2d_cl(feats[3], w["input_proj.3.0.weight:cl"], T, h5, w5, chs[3], 3, 3, 2, 1,
-                                      bias=w["input_proj.3.0.bias"], alloc=A)
+                                      bias=w["input_proj.3.0.bias"], alloc=A, splitk=sk,
+                                      ws=A(sk * T * h * ww * D) if sk > 1 else None)
             assert (ho, wo) == (h, ww)
         s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
         q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)

@@ -487,3 +487,21 @@ def test_gemm_unspecialised_epilogue_combinations(ops, act, res_mode):
         ref = F.relu(ref)
     out = ops.gemm(dev(a), dev(w), bias=dev(b), act=act, res=dev(r) if res_mode else None, res_mode=res_mode)
     close(out, ref, 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("T,H,W,cin,cout,stride,splits", [(5, 12, 20, 768, 256, 2, 8), (1, 9, 7, 64, 96, 1, 3), (2, 6, 10, 2048, 256, 2, 6)])
+def test_conv_splitk(ops, T, H, W, cin, cout, stride, splits):
+    """Split-K implicit-GEMM convolution (the level-3 3x3/s2 conv of C5: few output rows, K = 9*C5)."""
+    g = torch.Generator().manual_seed(cin + splits)
+    x = torch.randn(T, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, b, stride=stride, padding=1)
+    xcl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().cuda()
+    wcl = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    Ho, Wo = ref.shape[-2:]
+    ws = torch.empty(splits * T * Ho * Wo * cout, device="cuda")
+    out, ho, wo = ops.conv2d_cl(xcl, wcl, T, H, W, cin, 3, 3, stride, 1, bias=b.cuda(), splitk=splits, ws=ws)
+    assert (ho, wo) == (Ho, Wo)
+    got = out.view(T, Ho, Wo, cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 3e-4
