@@ -49,14 +49,16 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
-// Narrow rows (C <= 128: Swin stage 1): one HALF-wave per row, the row lives in one float4 per lane (read once),
-// statistics by xor-shuffles inside the 32 lanes.  The full-wave form above leaves 40 of 64 lanes idle at C = 96.
-__global__ void __launch_bounds__(256) layernorm_narrow_kernel(const float* __restrict__ x, const float* __restrict__ r,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                               long long M, int C, float eps) {
-  const int lane = threadIdx.x & 63, sub = lane & 31;
-  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+// Rows of up to 256 floats (Swin stage 1 and every d_model = 256 tensor of the transformer): the row lives in ONE
+// float4 per lane and is read once; LPR lanes per row (32 for C <= 128 -- the full-wave form above leaves 40 of 64
+// lanes idle at C = 96 -- else 64), statistics by xor-shuffles inside those lanes.
+template <int LPR>
+__global__ void __launch_bounds__(256) layernorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out,
+                                                            long long M, int C, float eps) {
+  const int lane = threadIdx.x & 63, sub = lane & (LPR - 1);
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + lane / LPR;
   const int n4 = C >> 2;
   const bool on = row < M && sub < n4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -66,12 +68,12 @@ __global__ void __launch_bounds__(256) layernorm_narrow_kernel(const float* __re
   }
   float s = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float mean = s / (float)C;
   const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
   float q = on ? (a * a + b * b) + (c * c + d * d) : 0.f;
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q / (float)C + eps);
   if (on) {
     const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[sub], bb = reinterpret_cast<const f32x4*>(beta)[sub];
@@ -413,7 +415,10 @@ extern "C" int tce_layernorm_f32(const float* x, const float* r, const float* ga
                     (!r || tce_aligned16(r)),
                 "tce_layernorm_f32: pointers must be 16-byte aligned");
   if (C <= 128)
-    hipLaunchKernelGGL(layernorm_narrow_kernel, dim3(tce_cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta,
+    hipLaunchKernelGGL(layernorm_reg_kernel<32>, dim3(tce_cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta,
+                       out, (long long)M, C, eps);
+  else if (C <= 256)
+    hipLaunchKernelGGL(layernorm_reg_kernel<64>, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta,
                        out, (long long)M, C, eps);
   else
     hipLaunchKernelGGL(layernorm_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, out,

@@ -123,7 +123,7 @@ def test_conv_implicit_gemm(ops, T, H, W, Cin, N, k, s, p):
     close(out.view(T, Ho, Wo, N).permute(0, 3, 1, 2), ref)
 
 
-@pytest.mark.parametrize("M,C", [(5, 96), (1000, 256), (77, 768), (33, 3072), (9, 4), (72001, 96), (1003, 128), (17, 132)])
+@pytest.mark.parametrize("M,C", [(5, 96), (1000, 256), (77, 768), (33, 3072), (9, 4), (72001, 96), (1003, 128), (17, 132), (24101, 256), (50, 192), (7, 260)])
 def test_layernorm(ops, M, C):
     g = torch.Generator().manual_seed(M + C)
     x, r = torch.randn(M, C, generator=g) * 3 + 1, torch.randn(M, C, generator=g)
