@@ -79,6 +79,12 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from tce_rvos_amd import build as _b
+    if not os.path.exists(_b.LIB):  # fresh checkout: the shared object is git-ignored; rank 0 builds, the others wait
+        if local_rank == 0:
+            _b.build(verbose=False)
+        if world > 1:
+            dist.barrier()
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks_async
 
