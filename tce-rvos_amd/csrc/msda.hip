@@ -258,6 +258,68 @@ __global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __rest
   if (active) out[item * D + d] = acc;
 }
 
+// 16-byte form of the plain (reference-signature) kernel: 8 lanes per (n, q, m) item, 4 channels per lane; lane i holds
+// sampling points i and i+8 (L*P <= 16).  Same arithmetic per channel as msda_plain_dev_kernel.
+__global__ void __launch_bounds__(256) msda_plain_q4_dev_kernel(const float* __restrict__ value,
+                                                                const int64_t* __restrict__ shapes,
+                                                                const int64_t* __restrict__ starts,
+                                                                const float* __restrict__ loc,
+                                                                const float* __restrict__ aw, float* __restrict__ out,
+                                                                int N, int S, int M, int Lq, int L, int P,
+                                                                long long total) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, gbase = lane & ~7;
+  const long long item = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool active = item < total;
+  const int LP = L * P;
+  int m = 0, n = 0;
+  if (active) {
+    long long r = item;
+    m = (int)(r % M); r /= M;
+    n = (int)(r / Lq);
+  }
+  float px[2] = {0.f, 0.f}, py[2] = {0.f, 0.f}, pw[2] = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pj = sub + 8 * e;
+    if (active && pj < LP) {
+      const long long base = item * LP + pj;
+      px[e] = loc[base * 2 + 0];
+      py[e] = loc[base * 2 + 1];
+      pw[e] = aw[base];
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const long long row_stride = (long long)M * D;
+  const float* vn = value + ((long long)n * S) * row_stride + m * D + sub * 4;
+  for (int j = 0; j < LP; ++j) {
+    const int src = gbase + (j & 7);
+    const bool hi = j >= 8;
+    const float x = __shfl(hi ? px[1] : px[0], src, 64), y = __shfl(hi ? py[1] : py[0], src, 64);
+    const float w = __shfl(hi ? pw[1] : pw[0], src, 64);
+    const int l = j / P;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+    if (active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+      const float* vbase = vn + (long long)starts[l] * row_stride;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
+      if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
+      if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
+      if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
+      if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+      const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += w * (c1 * v1[c] + c2 * v2[c] + c3 * v3[c] + c4 * v4[c]);
+    }
+  }
+  if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
+}
+
 }  // namespace
 
 extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -270,6 +332,12 @@ extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t*
   TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 32,
                 "tce_ms_deform_attn_forward_f32: bad sizes (L*P must be <= 32)");
   const long long total = (long long)N * Lq * M;
+  if (L * P <= 16 && tce_aligned16(value) && tce_aligned16(out)) {
+    hipLaunchKernelGGL(msda_plain_q4_dev_kernel, dim3(tce_cdiv(total, 32)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
+    TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
+    return TCE_OK;
+  }
   hipLaunchKernelGGL(msda_plain_dev_kernel, dim3(tce_cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
   TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
