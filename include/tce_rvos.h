@@ -218,6 +218,24 @@ int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* wo
 int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int32_t nheads, float scale, tceStream stream);
 int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
 
+/* Fused FFN / MLP, the hidden tensor kept on chip (csrc/chain.hip):
+ *     out[M,C] = LN_out?( x + W2 act( W1 LN_in?(x) + b1 ) + b2 )        act 1 ReLU | 2 GELU(erf)
+ * One launch replaces linear1 -> ReLU -> linear2 -> +residual -> LayerNorm of the transformer / VisionLanguageBlock
+ * FFNs (tce_deformable_transformer.py:489-491,548-552; segmentation.py:374-376) and norm2 -> fc1 -> GELU -> fc2 ->
+ * +residual of the Swin MLP (swin_transformer.py:28-47,255-256).  g_in/be_in (LayerNorm before W1; the residual is the
+ * un-normed x) and g_out/be_out (LayerNorm of the sum) are optional (NULL).  out may alias x.
+ * Weights are packed once (static): tce_ffn_pack_f32 takes W1 [Hd,C], b1 [Hd] (may be NULL), W2 [C,Hd] (nn.Linear
+ * layouts) and writes tce_ffn_packed_bytes(C,Hd) bytes: fp16 hi/lo planes in MFMA-fragment order.
+ * C in {96,128,192,256}, Hd % 32 == 0; row pitches ldx/ldo in floats (% 4 == 0); all pointers 16-byte aligned. */
+/* diagnostic: register (or clear with NULL) a device buffer of >= 1024*8 int64 for the fused FFN's in-kernel stamps */
+int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
+int64_t tce_ffn_packed_bytes(int32_t C, int32_t Hd);
+int tce_ffn_pack_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
+                     tceStream stream);
+int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in,
+                      const float* be_in, float eps_in, const float* g_out, const float* be_out, float eps_out,
+                      float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act, tceStream stream);
+
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */
 int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);

@@ -67,6 +67,10 @@ SIGNATURES = {
     "tce_embed_ln_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, f32, c_f]),
     "tce_mha_small64_f32": (i32, [c_f, c_f, i32, i32, f32, c_f]),
     "tce_tanh_f32": (i32, [c_f, c_f, i64, c_f]),
+    "tce_debug_ffn_set_stamp_buffer": (i32, [c_f]),
+    "tce_ffn_packed_bytes": (i64, [i32, i32]),
+    "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
+    "tce_ffn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f]),
     "tce_graph_begin": (i32, [c_f]),
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),

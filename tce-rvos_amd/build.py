@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
 # slowest first (they gate the parallel build): the GEMM translation units carry one epilogue body per (act, res) combination
-SOURCES = ["gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "gemm_h2.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
+SOURCES = ["chain.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "gemm_h2.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
            "text.hip", "resnet.hip", "frontend.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

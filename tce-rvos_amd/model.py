@@ -208,6 +208,15 @@ class ReferFormer(nn.Module):
                     w[pre + "qk.w"], w[pre + "qk.b"] = W[:2 * d], B[:2 * d]
                 if v_is_conv(sd[k]) and sd[k].shape[-1] == 3:
                     w[k + ":cl"] = sd[k].detach().permute(0, 2, 3, 1).reshape(sd[k].shape[0], -1).contiguous()
+            # fused FFN / Swin MLP streams (csrc/chain.hip): fp16 hi/lo planes in MFMA-fragment order
+            for k in list(sd):
+                for l1, l2, tag in ((".linear1.weight", ".linear2.weight", ".ffn:pk"),
+                                    (".mlp.fc1.weight", ".mlp.fc2.weight", ".mlp.ffn:pk")):
+                    if k.endswith(l1):
+                        pre = k[:-len(l1)]
+                        w1, w2 = sd[k].detach(), sd[pre + l2].detach()
+                        if w1.dim() == 2 and ops.ffn_supported(w1.shape[1], w1.shape[0]):
+                            w[pre + tag] = ops.ffn_pack(w1, sd[pre + l1[:-len("weight")] + "bias"].detach(), w2)
             if cfg.is_resnet:
                 self._pack_resnet(sd, w)
             if cfg.video:

@@ -436,3 +436,41 @@ def select_masks(pred_logits, pred_masks, out_hw, threshold=0.5):
                                     out.data_ptr(), best.data_ptr(), T, Q, K, h, w, H0, W0, float(threshold), _stream()),
           "tce_select_masks_u8")
     return out, best
+
+
+def ffn_pack(w1, b1, w2):
+    """Packs nn.Linear weights W1 [Hd,C], b1 [Hd], W2 [C,Hd] into the fused-FFN stream (csrc/chain.hip): fp16 hi/lo
+    planes in MFMA-fragment order.  Done once per load_state_dict."""
+    _chk(w1, "w1")
+    _chk(w2, "w2")
+    Hd, Cn = w1.shape
+    if tuple(w2.shape) != (Cn, Hd):
+        raise ValueError("ffn_pack: W2 must be [C, Hd]")
+    nbytes = lib().tce_ffn_packed_bytes(Cn, Hd)
+    if nbytes < 0:
+        raise ValueError(f"ffn_pack: unsupported shape C={Cn} hidden={Hd}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    check(lib().tce_ffn_pack_f32(w1.contiguous().data_ptr(), b1.contiguous().data_ptr() if b1 is not None else None,
+                                 w2.contiguous().data_ptr(), out.data_ptr(), Cn, Hd, _stream()), "tce_ffn_pack_f32")
+    return out
+
+
+def ffn_supported(Cn, Hd):
+    return lib().tce_ffn_packed_bytes(int(Cn), int(Hd)) > 0
+
+
+def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_out=1e-5, out=None, M=None):
+    """out = LN_out?(x + W2 act(W1 LN_in?(x) + b1) + b2); x [M, C] (row pitch = x.stride(0)); ln_* = (gamma, beta)."""
+    _chk(x, "x")
+    Cn = x.shape[-1]
+    if M is None:
+        M = x.numel() // Cn
+    ldx = x.stride(0) if x.dim() == 2 else Cn
+    if out is None:
+        out = x
+    ldo = out.stride(0) if out.dim() == 2 else Cn
+    gi, bi = (ln_in[0].data_ptr(), ln_in[1].data_ptr()) if ln_in is not None else (None, None)
+    go, bo = (ln_out[0].data_ptr(), ln_out[1].data_ptr()) if ln_out is not None else (None, None)
+    check(lib().tce_ffn_fused_f32(x.data_ptr(), ldx, packed.data_ptr(), b2.data_ptr(), gi, bi, eps_in, go, bo, eps_out,
+                                  out.data_ptr(), ldo, M, Cn, Hd, act, _stream()), "tce_ffn_fused_f32")
+    return out

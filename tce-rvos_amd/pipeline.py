@@ -13,6 +13,9 @@ from .ops import ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RES, RES_ADD, RES_MUL, gemm_
 
 D = 256
 NH = 8
+# Rows from which the fused FFN kernel (one workgroup = 128 tokens x the whole hidden extent, ~150 us at hidden 2048)
+# beats two GEMM launches: it needs about half the chip's CUs busy.
+FFN_FUSED_MIN_ROWS = int(__import__("os").environ.get("TCE_FFN_FUSED_MIN_ROWS", 16000))
 
 
 def _lin(A, x, M, K, w, b, N, **kw):
@@ -143,8 +146,17 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
 
-    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar):
-        """x <- x + W2 relu(W1 x) (in place)."""
+    def ln_(x, pre):
+        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
+
+    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
+        """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
+        (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
+        pk = w.get(pre + "ffn:pk")
+        if pk is not None and M >= FFN_FUSED_MIN_ROWS:
+            ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
+                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
+            return
         A = ar.alloc
         m1 = ar.mark()
         hdn = A(M, ff)
@@ -153,9 +165,8 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
                 res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
         ar.release(m1)
-
-    def ln_(x, pre):
-        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
+        if norm:
+            ln_(x, norm)
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
              ar=ar):
@@ -213,12 +224,10 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             ln_(src, fp + "norm3")
             ar.release(m0)
             # (4) FFN over all pixels (:489-491)
-            ffn(src, T * S, fp)
-            ln_(src, fp + "norm4")
+            ffn(src, T * S, fp, norm=fp + "norm4")
         msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src)
         ln_(src, lp + "norm1")
-        ffn(src, T * S, lp)
-        ln_(src, lp + "norm2")
+        ffn(src, T * S, lp, norm=lp + "norm2")
     memory = src
 
     _stage("encoder")
@@ -255,8 +264,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             ln_(tgt, lp + "norm2")
             msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar)
             ln_(tgt, lp + "norm1")
-            ffn(tgt, T * Q, lp, ar=dar)
-            ln_(tgt, lp + "norm3")
+            ffn(tgt, T * Q, lp, ar=dar, norm=lp + "norm3")
             if cfg.with_box_refine:
                 bp = f"bbox_embed.{lid}.layers."
                 t1 = A(T * Q, D)
@@ -379,11 +387,17 @@ def _swin_backbone(model, frames, ar, sizes):
                                       C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
             gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
                     res_mode=RES_ADD)
-            ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
-            hdn = A(ntok, hid)
-            gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"], act=ACT_GELU)
-            gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
-                    ldres=C, res_mode=RES_ADD)
+            pk = w.get(p + "mlp.ffn:pk")
+            if pk is not None and ntok >= FFN_FUSED_MIN_ROWS:  # norm2 -> fc1 -> GELU -> fc2 -> +x in one launch
+                ops.ffn_fused(x, pk, w[p + "mlp.fc2.bias"], hid, ACT_GELU, M=ntok,
+                              ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
+            else:
+                ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
+                hdn = A(ntok, hid)
+                gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
+                        act=ACT_GELU)
+                gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
+                        ldres=C, res_mode=RES_ADD)
             ar.release(m0)
         if cfg.video:
             feats.append(x)
@@ -509,8 +523,7 @@ def _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, 
                     ldres=D, res_mode=RES_ADD)
             ar.release(m1)
             ln_(tgt, bp + "norm2")
-            ffn(tgt, T * hw, bp)
-            ln_(tgt, bp + "norm3")
+            ffn(tgt, T * hw, bp, norm=bp + "norm3")
         # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
         if y is not None:
             ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)

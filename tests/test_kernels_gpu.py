@@ -505,3 +505,64 @@ def test_conv_splitk(ops, T, H, W, cin, cout, stride, splits):
     assert (ho, wo) == (Ho, Wo)
     got = out.view(T, Ho, Wo, cout).permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize("M,C,Hd,act,ln", [
+    (24100, 256, 2048, "relu", "out"),   # encoder / FTF FFN (tce_deformable_transformer.py:489-491,548-552)
+    (18000, 256, 2048, "relu", "out"),   # VisionLanguageBlock FFN, stride 8 (segmentation.py:374-376)
+    (72000, 256, 2048, "relu", "out"),   # stride 4
+    (72000, 96, 384, "gelu", "in"),      # Swin-T stage-1 MLP (swin_transformer.py:28-47,255-256)
+    (4600, 192, 768, "gelu", "in"),
+    (1201, 128, 512, "gelu", "in"),      # Swin-B widths, ragged row count
+    (77, 256, 1024, "gelu", "in"),
+    (333, 256, 64, "relu", "both"),
+    (129, 96, 96, "relu", "none"),
+])
+def test_ffn_fused(ops, M, C, Hd, act, ln):
+    """The fused FFN / MLP launch (hidden tensor on chip) against torch fp32 of the op sequence it replaces; the
+    accuracy class is checked against fp64 on a slice of rows."""
+    g = torch.Generator().manual_seed(M + C + Hd)
+    x = torch.randn(M, C, generator=g)
+    w1 = torch.randn(Hd, C, generator=g) / math.sqrt(C)
+    b1 = torch.randn(Hd, generator=g) * 0.2
+    w2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd)
+    b2 = torch.randn(C, generator=g) * 0.2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gam2, bet2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+
+    def ref(x_, dt):
+        y = F.layer_norm(x_, (C,), gam.to(dt), bet.to(dt), 1e-5) if ln in ("in", "both") else x_
+        h = F.linear(y, w1.to(dt), b1.to(dt))
+        h = torch.relu(h) if act == "relu" else F.gelu(h)
+        o = x_ + F.linear(h, w2.to(dt), b2.to(dt))
+        return F.layer_norm(o, (C,), gam2.to(dt), bet2.to(dt), 1e-5) if ln in ("out", "both") else o
+
+    pk = ops.ffn_pack(dev(w1), dev(b1), dev(w2))
+    xd = dev(x)
+    out = torch.empty_like(xd)
+    ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU if act == "relu" else ops.ACT_GELU,
+                  ln_in=(dev(gam), dev(bet)) if ln in ("in", "both") else None,
+                  ln_out=(dev(gam2), dev(bet2)) if ln in ("out", "both") else None, out=out)
+    rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 200), M)]).unique()
+    r32 = ref(x[rows], torch.float32)
+    close(out[rows.cuda()], r32, 2e-4, 2e-4)
+    r64 = ref(x[rows].double(), torch.float64)
+    e_kernel = (out[rows.cuda()].cpu().double() - r64).abs().max().item()
+    e_torch = (r32.double() - r64).abs().max().item()
+    assert e_kernel <= 8 * e_torch + 1e-6, f"fused FFN error {e_kernel:.3e} vs torch-fp32 error {e_torch:.3e} (both vs fp64)"
+    # in place (out aliases x), as the pipeline calls it
+    ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU if act == "relu" else ops.ACT_GELU,
+                  ln_in=(dev(gam), dev(bet)) if ln in ("in", "both") else None,
+                  ln_out=(dev(gam2), dev(bet2)) if ln in ("out", "both") else None)
+    assert torch.equal(xd, out)
+
+
+def test_ffn_fused_rejects_bad_arguments(ops):
+    from tce_rvos_amd._lib import TceError
+    with pytest.raises(ValueError):
+        ops.ffn_pack(dev(torch.zeros(64, 100)), None, dev(torch.zeros(100, 64)))   # C = 100 unsupported
+    w1, w2 = dev(torch.zeros(64, 96)), dev(torch.zeros(96, 64))
+    pk = ops.ffn_pack(w1, None, w2)
+    x = dev(torch.zeros(10, 96))
+    with pytest.raises(TceError):
+        ops.ffn_fused(x, pk, dev(torch.zeros(96)), 64, 0)   # no activation code 0
