@@ -6,15 +6,21 @@
 
 A "step" = one B=1 clip forward on every rank: Swin-T backbone, T=5 frames of 360x640, a 32-token text
 (RoBERTa-base, random init, evaluated every step as the reference does), FTF/IQT deformable transformer,
-cross-modal FPN, dynamic mask head -- BASELINE.json config 2 -- followed (N > 1) by the RCCL all-gather of the
-per-clip mask logits.  Clips are independent units sharded over ranks (weak scaling, no data-path collective
-besides the gather).  Inputs and weights are synthetic and already resident in HBM when the timed region starts.
+cross-modal FPN, dynamic mask head -- BASELINE.json config 2 -- followed (N > 1) by the caller harness kernel
+(best query, resize, sigmoid, threshold) and the RCCL all-gather of the per-clip uint8 masks.  Clips are independent
+units sharded over ranks (weak scaling, no data-path collective besides the gather).  Inputs and weights are
+synthetic and already resident in HBM when the timed region starts.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : the dominant kernel (fp32 MFMA GEMM, 128x128 tile) -- algorithmic FLOPs of its launches in one
-                 step / their summed launch durations, measured with events on the launch stream in a second,
-                 instrumented pass over the same K steps (the headline `value` comes from the un-instrumented pass).
-  cpu_baseline : the CPU oracle (a port of the reference path) timed on this box's host cores, rank 0, N=1 only.
+Prints ONE JSON line (rank 0).  Extra objects / fields:
+  roofline          : the kernel that carries the most algorithmic FLOPs of a step -- its FLOPs / its summed launch
+                      durations, measured live with events on the launch stream in a second, instrumented (eager) pass
+                      (the headline `value` comes from the un-instrumented pass).  `traffic` is NOT measured by this
+                      run: it is read from the committed PMC summary named in `traffic_source` (or null).
+  cpu_baseline      : the CPU oracle (a port of the reference path) timed on this box's host cores, rank 0, N=1 only.
+  value_f32_exact   : clips/s of the same step with every GEMM on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32) instead
+                      of the 3 x fp16 split (N=1 only, short pass).
+  value_text_cached : clips/s with the per-expression text cache on (RoBERTa evaluated once per distinct caption
+                      instead of every clip like the reference; N=1 only, short pass).
 """
 import argparse
 import json
@@ -27,25 +33,44 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def _pmc_traffic(prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc passes of
-    this same command: profiles/r01_pmc_traffic.json).  None when no summary matches."""
+def _pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command, aggregated by tools/pmc_traffic.py).  (None, None) when absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             k = json.load(f)["kernels"]
-        hits = [v for name, v in k.items() if name.startswith(prefix) and ", false, false" in name]
-        return round(hits[0]["hbm_bytes_per_launch"]) if hits else None
-    except Exception:
-        return None
+        hits = [v for name, v in k.items() if name.startswith(kernel_prefix)]
+        return (round(hits[0]["hbm_bytes_per_launch"]), PMC_SUMMARY + " (rocprofv3 --pmc passes, not this run)") if hits \
+            else (None, None)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def _ensure_built(local_rank, world):
+    """Fresh checkout: the shared object is git-ignored.  Runs BEFORE any GPU / RCCL call (the compiler children must
+    not be spawned from a process that has initialised the GPU); local rank 0 builds (the linker output is renamed
+    into place atomically, tce_rvos_amd/build.py), the other ranks wait for the file."""
+    from tce_rvos_amd import build as _b
+    if os.path.exists(_b.LIB):
+        return
+    if local_rank == 0:
+        _b.build(verbose=False)
+    else:
+        t0 = time.time()
+        while not os.path.exists(_b.LIB):
+            if time.time() - t0 > 1800:
+                raise SystemExit("bench.py: timed out waiting for local rank 0 to build libtce_rvos.so")
+            time.sleep(1.0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: ~2.3 s of timed region at config 2)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--height", type=int, default=360)
     ap.add_argument("--width", type=int, default=640)
@@ -53,6 +78,7 @@ def main():
     ap.add_argument("--backbone", default="swin_t_p4w7")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the value_f32_exact / value_text_cached passes")
     ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (+ TCE_BENCH_ONE_DEVICE=1: every rank on cuda:0) rehearses the N>1 control flow on a 1-GPU box")
@@ -60,15 +86,16 @@ def main():
                     help="independent B=1 clip forwards kept in flight per GPU and per step (one stream + replay slot each)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    _ensure_built(local_rank, world)
+
+    import torch
+    import torch.distributed as dist
+
     if os.environ.get("TCE_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -79,12 +106,6 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from tce_rvos_amd import build as _b
-    if not os.path.exists(_b.LIB):  # fresh checkout: the shared object is git-ignored; rank 0 builds, the others wait
-        if local_rank == 0:
-            _b.build(verbose=False)
-        if world > 1:
-            dist.barrier()
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks_async
 
@@ -93,43 +114,48 @@ def main():
     model, _, _ = build_model(margs)
     model = model.to(dev).eval()
     ops.set_gemm_mode(args.gemm_mode)
+    C = max(1, args.clips_in_flight)
+    if C > 1 and not model.use_graph:
+        raise SystemExit("--clips-in-flight > 1 needs graph replay (TCE_GRAPH=1): eager launches share one stream per slot")
 
     T, H, W = args.frames, args.height, args.width
     g = torch.Generator().manual_seed(1234 + rank)
     n_pool = 4
     clips = [torch.randn(T, 3, H, W, generator=g).to(dev) for _ in range(n_pool)]
-    ids = torch.randint(3, 50264, (n_pool, 1, args.tokens), generator=g)
-    ids[:, :, 0], ids[:, :, -1] = 0, 2
-    ids = ids.to(dev)
+    ids_host = torch.randint(3, 50264, (n_pool, 1, args.tokens), generator=g)
+    ids_host[:, :, 0], ids_host[:, :, -1] = 0, 2
+    ids = ids_host.to(dev)
     targets = [{"size": torch.tensor([H, W])}]
     gather_buf, pending = None, None
-
-    C = max(1, args.clips_in_flight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(C)] if C > 1 else None
+    use_host_ids = False  # the text-cache pass keys the cache on host ids
+
+    def one(i, slot=0):
+        tok = ids_host[i % n_pool] if use_host_ids else ids[i % n_pool]
+        return model([clips[i % n_pool]], tok, targets, slot=slot)
 
     def step(i, gather=True):
         nonlocal gather_buf, pending
         if C == 1:
-            out = model([clips[i % n_pool]], ids[i % n_pool], targets)
-            local = out["pred_masks"]
+            outs = [one(i)]
         else:  # C independent B=1 forwards in flight, one per stream / replay slot
             cur = torch.cuda.current_stream()
             outs = []
             for c in range(C):
                 streams[c].wait_stream(cur)
                 with torch.cuda.stream(streams[c]):
-                    outs.append(model([clips[(i * C + c) % n_pool]], ids[(i * C + c) % n_pool], targets, slot=c))
+                    outs.append(one(i * C + c, slot=c))
             for c in range(C):
                 cur.wait_stream(streams[c])
-            out = outs[0]
-            local = torch.cat([o["pred_masks"] for o in outs], 0)
         if world > 1 and gather:
-            # the masks of all world*C clips of this step meet on every rank; the collective of step i runs on RCCL's
-            # stream while step i+1 computes, and is completed (stream-ordered) before step i+1's own gather starts
+            # what meets on every rank is what the callers keep: the harness's uint8 masks (inference_ytvos.py:238-250
+            # on the GPU), 4x fewer bytes than the fp32 logits.  The collective of step i runs on RCCL's stream while
+            # step i+1 computes, and is completed (stream-ordered) before step i+1's own gather starts.
+            local = torch.stack([ops.select_masks(o["pred_logits"][0], o["pred_masks"][0], (H, W))[0] for o in outs], 0)
             if pending is not None:
                 gather_buf = pending.wait()
             pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C)
-        return out
+        return outs[0]
 
     def fence():
         nonlocal gather_buf, pending
@@ -140,26 +166,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(n_steps, n_warm, gather=True):
+        for i in range(n_warm):
+            step(i, gather)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i, gather)
+        fence()
+        return time.perf_counter() - t0
+
+    elapsed = timed(args.steps, args.warmup)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ops.check_range(dev)  # split-fp16 range guard: a tripped flag invalidates the number
 
     roofline = None
-    C_saved, C = C, 1  # the instrumented pass and the parity check run one clip at a time
+    C_saved, C = C, 1  # the instrumented pass, the variants and the parity check run one clip at a time
+    solo = rank == 0 and world == 1
     if rank == 0 and not args.no_roofline:
+        n_inst = min(args.steps, 40)
         graph_mode, model.use_graph = model.use_graph, False  # per-launch events need eager launches
         step(0, gather=False)  # rank-0-only passes must not enter the collective
         ops.GEMM_PROFILE = []
-        for i in range(args.steps):
+        for i in range(n_inst):
             step(i, gather=False)
         torch.cuda.synchronize()
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
@@ -177,22 +209,39 @@ def main():
         # (dense fp16 peak 2500 TFLOP/s): `achieved` stays ALGORITHMIC 2*M*N*K, the MFMA pipe issues 3x that.
         peak = 157.3 if mode == "f32" else 2500.0
         ach = fl / sec / 1e12
-        gemm_sec_per_step = sum(v[1] for v in agg.values()) / args.steps
-        tname = {256128: "256,128", 128128: "128,128", 12864: "128,64", 6464: "64,64", 6465: "64,64"}[key[0]]
-        kname = "gemm_f32_kernel" if mode == "f32" else "gemm_f16x3_kernel"
-        roofline = {"bound": "mfma", "kernel": f"{kname}<{tname},{'true' if key[1] else 'false'}>", "gemm_mode": mode,
+        if isinstance(key[0], str):
+            kname = key[0]
+        else:
+            tname = {256128: "256, 128", 128128: "128, 128", 12864: "128, 64", 6464: "64, 64", 6465: "64, 64"}[key[0]]
+            kname = ("gemm_f32_kernel" if mode == "f32" else "gemm_f16x3_kernel") + f"<{tname}" + (" conv>" if key[1] else ">")
+        traffic, tsrc = _pmc_traffic(kname.split(" conv")[0].rstrip(">"))
+        roofline = {"bound": "mfma", "kernel": kname, "gemm_mode": mode,
                     "mfma_issued_tflops": round(ach * (1 if mode == "f32" else 3), 2),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    # what a bare loop of this MFMA + its LDS fragment feed sustains with all 256 CUs issuing
-                    # (tools/mfma_peak.py: clock-limited); informative, `peak` stays the guide's figure
+                    # what a bare loop of this MFMA + an LDS fragment feed sustains with all 256 CUs issuing: the chip
+                    # lowers its clock under matrix load; informative, `peak` stays the guide's
                     "sustained_mfma_ceiling_tflops": None if mode == "f32" else 1650.0,
-                    "traffic": _pmc_traffic(f"{kname}<{tname.replace(',', ', ')}"), "launches_per_step": n // args.steps,
-                    "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
-                    "all_gemm_ms_per_step": round(gemm_sec_per_step * 1e3, 3),
-                    "all_gemm_tflops": round(sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12, 2)}
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "launches_per_step": n // n_inst, "avg_launch_us": round(sec / n * 1e6, 2),
+                    "flops_per_launch_avg": fl / n, "instrumented_steps": n_inst,
+                    "all_mfma_kernels_ms_per_step": round(sum(v[1] for v in agg.values()) / n_inst * 1e3, 3),
+                    "all_mfma_kernels_tflops": round(sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12, 2)}
+
+    variants = {}
+    if solo and not args.no_variants:
+        n_var = max(10, min(args.steps, 60))
+        model.text_cache_size, use_host_ids = 8, True
+        variants["value_text_cached"] = round(n_var / timed(n_var, 6, gather=False), 3)
+        model.text_cache_size, use_host_ids = 0, False
+        if args.gemm_mode == "f16x3":
+            ops.set_gemm_mode("f32")
+            model.repack()  # captured graphs hold the split-mode kernels
+            variants["value_f32_exact"] = round(n_var / timed(n_var, 6, gather=False), 3)
+            ops.set_gemm_mode("f16x3")
+            model.repack()
 
     cpu_baseline, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         from oracle import tce_oracle as O
         cores = min(32, os.cpu_count() or 1)  # oneDNN/MKL scale poorly past ~32 threads on this graph
         torch.set_num_threads(cores)
@@ -213,8 +262,9 @@ def main():
         out = step(0, gather=False)
         torch.cuda.synchronize()
         pm = out["pred_masks"].cpu()
+        err = float((pm - ref["pred_masks"]).abs().max())
         parity = {"mask_iou_vs_oracle": round(O.mask_iou(pm > 0, ref["pred_masks"] > 0), 6),
-                  "max_abs_logit_err": float((pm - ref["pred_masks"]).abs().max()),
+                  "max_abs_logit_err": err, "max_rel_logit_err": err / float(ref["pred_masks"].abs().max()),
                   # pixels where a sign flip is numerically meaningless
                   "frac_pixels_abs_logit_lt_1e-3": float((ref["pred_masks"].abs() < 1e-3).float().mean())}
 
@@ -223,17 +273,22 @@ def main():
         known = {("resnet50", 1, 360, 640): "BASELINE config 1", ("swin_t_p4w7", 5, 360, 640): "BASELINE config 2",
                  ("video_swin_t_p4w7", 8, 384, 640): "BASELINE config 3", ("swin_b_p4w7", 10, 480, 854): "BASELINE config 5"}
         cfg_name = known.get((args.backbone, T, H, W), "not a BASELINE config")
+        metric = METRIC if cfg_name == "BASELINE config 2" else \
+            f"clips/s (T={T}, {H}×{W}, {args.backbone}; {cfg_name}) at {world} MI355X; mask IoU vs ref"
         clips_total = args.steps * world * C
-        line = {"metric": METRIC, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+        line = {"metric": metric, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.gemm_mode == "f32" else "f32 (3xf16-split MFMA, f32 accumulate)", "data": "synthetic",
+                "timed_region_s": round(elapsed, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.gemm_mode == "f32" else "f32 (3xf16-split MFMA, f32 accumulate)", "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
                            "clips_per_step": world * C, "clips_in_flight_per_gpu": C,
                            "parallelism": f"clip-sharded x{world}" +
-                                                                   (" + RCCL all_gather(pred_masks)" if world > 1 else "")},
+                                          (" + harness kernel + RCCL all_gather(uint8 masks)" if world > 1 else "")},
                 "launch": "hipGraph replay" if model.use_graph else "eager",
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
+        line.update(variants)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -60,27 +60,15 @@ int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
 int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t conv);
 /* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
  * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
-int tce_gemm_force_tile(int32_t tile); /* tuning aid: 0 = automatic */
-/* diagnostic: register (or clear with NULL) a device buffer of >= 2048*8 int64 for in-kernel s_memtime stamps */
-int tce_debug_set_stamp_buffer(long long* dev_buf);
-/* same for the prototype GEMM (tce_gemm_h2_f32): >= 256*8*8 int64, per-wave phase sums */
-int tce_debug_h2_set_stamp_buffer(long long* dev_buf);
-/* diagnostic: bare fp16 MFMA loop (12 MFMAs x iters per wave) on `blocks` workgroups of `threads` threads; out needs
- * blocks*threads floats.  mode 0 registers only, 1/2 with the GEMM's LDS fragment feed, 3 plus a barrier per 24 MFMAs. */
-int tce_debug_mfma_peak(float* out, int32_t blocks, int32_t threads, int32_t iters, int32_t mode, tceStream stream);
-int tce_debug_set_epilogue(int32_t lds_staged); /* tuning aid: 1 (default) LDS-staged coalesced stores, 0 direct */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 
-/* PROTOTYPE of the next GEMM generation: operands pre-split into fp16 planes in HBM
- * (tce_split_f16_f32: hi = f16_rtz(x (+add)), lo = f16_rtz(x - hi)), K slices staged HBM -> LDS by DMA into a 3-stage
- * ring; same arithmetic and epilogue as tce_gemm_f32's split mode.  A/W planes [rows, K] fp16, pitches in halfs. */
-int tce_split_f16_f32(const float* x, const float* add, void* hi, void* lo, int64_t rows, int32_t cols,
-                      int64_t add_rows, tceStream stream);
-int tce_gemm_h2_f32(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias, const float* res,
-                    float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres,
-                    int32_t act, int32_t res_mode, int64_t a_slice /* 0/32: row-major A; M*32 with lda=32: K-slice-major A [K/32][M][32] */,
-                    tceStream stream);
+/* Operand-range guard of the split-fp16 arithmetic (its operands must lie inside the fp16 range, |x| < 65504: larger
+ * values saturate silently in v_cvt_pkrtz).  Weights are checked on the host when they are packed; activations are
+ * checked where they are PRODUCED: every GEMM / fused-FFN epilogue of the split mode sets *flag = 1 when it stores a
+ * value with |v| >= 60000 or a NaN.  `flag` is a device int32 owned by the caller (NULL disables the check); the caller
+ * reads and clears it at its own synchronisation points (tce_rvos_amd.ops.check_range). */
+int tce_set_range_flag(int32_t* flag);
 
 /* LayerNorm over the last dim: out[m,:] = LN(x[m,:] (+ r[m,:])) * gamma + beta.   r may be NULL.
  * Reference: nn.LayerNorm call sites (swin_transformer.py:213,255; tce_deformable_transformer.py:454,...). */
@@ -210,11 +198,14 @@ int tce_resize_v_norm_f32(const uint8_t* tmp, const int32_t* coef, const int32_t
 
 /* RoBERTa text encoder (models/tce_rvos.py:406-424; HuggingFace RobertaModel arithmetic) -- the pieces not covered
  * by tce_gemm_f32 / tce_layernorm_f32:
- *   tce_embed_ln_f32     out[t] = LayerNorm(word[ids[t]] + position[pos_ids[t]] + token_type[0])   (ids int64, device)
+ *   tce_embed_ln_f32     out[t] = LayerNorm(word[ids[t]] + position[pos_ids[t]] + token_type[0])   (ids int64, device);
+ *                        pos_ids NULL: derived in-kernel as HF's create_position_ids_from_input_ids does
+ *                        (pad_id + running count of non-pad tokens; pad tokens -> pad_id)
  *   tce_mha_small64_f32  self-attention core over packed qkv [L, 3*nheads*64] (head_dim 64, L <= 128) -> [L, nheads*64]
  *   tce_tanh_f32         pooler activation */
 int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
-                     const float* gamma, const float* beta, float* out, int32_t L, int32_t C, float eps, tceStream stream);
+                     const float* gamma, const float* beta, float* out, int32_t L, int32_t C, float eps, int32_t pad_id,
+                     tceStream stream);
 int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int32_t nheads, float scale, tceStream stream);
 int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
 
@@ -227,8 +218,6 @@ int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
  * Weights are packed once (static): tce_ffn_pack_f32 takes W1 [Hd,C], b1 [Hd] (may be NULL), W2 [C,Hd] (nn.Linear
  * layouts) and writes tce_ffn_packed_bytes(C,Hd) bytes: fp16 hi/lo planes in MFMA-fragment order.
  * C in {96,128,192,256}, Hd % 32 == 0; row pitches ldx/ldo in floats (% 4 == 0); all pointers 16-byte aligned. */
-/* diagnostic: register (or clear with NULL) a device buffer of >= 1024*8 int64 for the fused FFN's in-kernel stamps */
-int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
 int64_t tce_ffn_packed_bytes(int32_t C, int32_t Hd);
 int tce_ffn_pack_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
                      tceStream stream);

@@ -1,0 +1,20 @@
+/* tce_rvos_debug.h -- tuning and diagnostic entry points of libtce_rvos.so.  NOT part of the drop-in ABI
+ * (include/tce_rvos.h): nothing on the product path calls these; tools/ and the profiling scripts do. */
+#ifndef TCE_RVOS_DEBUG_H
+#define TCE_RVOS_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* tuning aid: force the output tile of the GEMM entry point (0 = automatic) */
+int tce_gemm_force_tile(int32_t tile);
+/* register (or clear with NULL) a device buffer of >= 2048*8 int64 for the split GEMM's in-kernel s_memtime stamps */
+int tce_debug_set_stamp_buffer(long long* dev_buf);
+/* tuning aid: 1 (default) LDS-staged coalesced GEMM epilogue stores, 0 direct row-per-lane stores */
+int tce_debug_set_epilogue(int32_t lds_staged);
+/* register (or clear with NULL) a device buffer of >= 1024*8 int64 for the fused FFN's in-kernel stamps */
+int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
+#ifdef __cplusplus
+}
+#endif
+#endif

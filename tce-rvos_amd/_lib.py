@@ -31,15 +31,9 @@ SIGNATURES = {
     "tce_gemm_splitk_f32": (i32, [C.POINTER(GemmArgs), i32, c_f, c_f]),
     "tce_gemm_select_tile": (i32, [i32, i32, i32]),
     "tce_gemm_select_tile_ex": (i32, [i32, i32, i32, i32, i32]),
-    "tce_gemm_force_tile": (i32, [i32]),
-    "tce_debug_set_stamp_buffer": (i32, [c_f]),
-    "tce_debug_h2_set_stamp_buffer": (i32, [c_f]),
-    "tce_debug_mfma_peak": (i32, [c_f, i32, i32, i32, i32, c_f]),
-    "tce_debug_set_epilogue": (i32, [i32]),
     "tce_set_gemm_mode": (i32, [i32]),
+    "tce_set_range_flag": (i32, [c_f]),
     "tce_get_gemm_mode": (i32, []),
-    "tce_split_f16_f32": (i32, [c_f, c_f, c_f, c_f, i64, i32, i64, c_f]),
-    "tce_gemm_h2_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, c_f]),
     "tce_layernorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, c_f]),
     "tce_groupnorm_nsplit": (i32, [i32]),
     "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),
@@ -64,10 +58,9 @@ SIGNATURES = {
     "tce_mask_pack_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_mask_tail_f32": (i32, [c_f, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, f32, f32, i32, c_f]),
     "tce_select_masks_u8": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, f32, c_f]),
-    "tce_embed_ln_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, f32, c_f]),
+    "tce_embed_ln_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, f32, i32, c_f]),
     "tce_mha_small64_f32": (i32, [c_f, c_f, i32, i32, f32, c_f]),
     "tce_tanh_f32": (i32, [c_f, c_f, i64, c_f]),
-    "tce_debug_ffn_set_stamp_buffer": (i32, [c_f]),
     "tce_ffn_packed_bytes": (i64, [i32, i32]),
     "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tce_ffn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f]),
@@ -75,6 +68,14 @@ SIGNATURES = {
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),
     "tce_graph_destroy": (i32, [C.c_void_p]),
+}
+
+# include/tce_rvos_debug.h: tuning / diagnostic entry points (tools/ only)
+DEBUG_SIGNATURES = {
+    "tce_gemm_force_tile": (i32, [i32]),
+    "tce_debug_set_stamp_buffer": (i32, [c_f]),
+    "tce_debug_set_epilogue": (i32, [i32]),
+    "tce_debug_ffn_set_stamp_buffer": (i32, [c_f]),
 }
 
 _LIB = None
@@ -92,7 +93,7 @@ def lib():
             raise TceError(f"{LIB_PATH} not found: build the HIP extension first "
                            f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(l, name)  # AttributeError if the symbol is absent
             fn.restype = res
             fn.argtypes = args

@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
 # slowest first (they gate the parallel build): the GEMM translation units carry one epilogue body per (act, res) combination
-SOURCES = ["chain.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "gemm_h2.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
+SOURCES = ["chain.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
            "text.hip", "resnet.hip", "frontend.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -51,10 +51,12 @@ def build(verbose=True, force=False):
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         list(pool.map(run, todo))
     if force or _newer(objs, LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        tmp = LIB + f".tmp{os.getpid()}"  # link beside the target, rename into place: no reader ever sees a partial file
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     return LIB
 
 

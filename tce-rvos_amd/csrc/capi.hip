@@ -12,6 +12,13 @@ void tce_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static int* g_range_flag = nullptr;
+int* tce_range_flag() { return g_range_flag; }
+extern "C" int tce_set_range_flag(int32_t* flag) {
+  g_range_flag = flag;
+  return TCE_OK;
+}
+
 extern "C" int tce_abi_version(void) { return 1; }
 extern "C" const char* tce_last_error(void) { return g_err; }
 

@@ -31,7 +31,9 @@
 // C <= 128 runs 8 waves (two per SIMD).  Per-wave LDS traffic: 64 ds_read_b128 per 96 MFMAs; per-CU fill:
 // 65 KiB per iteration.  Algorithmic HBM bytes: x read + out written (2 * M * C * 4) + the weight stream once per XCD.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/tce_rvos.h"
+#include "../../include/tce_rvos_debug.h"
 
 namespace {
 
@@ -87,6 +89,7 @@ struct FfnArgs {
   long long ldx, ldo;
   int M, NI;  // NI = hidden/32 + 1 iterations
   float eps_in, eps_out;
+  int* range_flag;  // tce_set_range_flag: set when a hidden or an output value leaves the fp16 range of the split
 };
 
 template <int C, int WAVES, int ACT>
@@ -187,6 +190,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+  tce_amax_t amax = 0;
   h16x8 hh0, hl0, hh1, hl1;  // H^T of the previous chunk as B fragments (k-steps 0 and 1)
 #pragma unroll
   for (int j = 0; j < 8; ++j) hh0[j] = hl0[j] = hh1[j] = hl1[j] = (_Float16)0.f;
@@ -249,6 +253,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
             v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f));
             v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
           }
+          amax = max(amax, max(tce_absbits(v0), tce_absbits(v1)));
           const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(v0, v1);
           const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz(v0 - (float)a[0], v1 - (float)a[1]);
           unsigned wa = __builtin_bit_cast(unsigned, a), wb = __builtin_bit_cast(unsigned, b);
@@ -333,9 +338,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = oacc[t][4 * g + c];
+        amax = tce_amax4(amax, o);
         *reinterpret_cast<f32x4*>(po + 32 * t + 8 * g) = o;
       }
   }
+  tce_range_report(p.range_flag, amax);
   if (stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamps[3] = (long long)__builtin_amdgcn_s_memtime();
@@ -441,7 +448,7 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   FfnArgs a;
   a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2;
   a.g_in = g_in; a.be_in = be_in; a.g_out = g_out; a.be_out = be_out;
-  a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out;
+  a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag();
   hipStream_t s = (hipStream_t)stream;
   if (C == 256) ffn_launch<256, 4>(a, act, s);
   else if (C == 192) ffn_launch<192, 4>(a, act, s);

@@ -10,6 +10,9 @@
 #define TCE_ELAUNCH (-2)
 
 void tce_set_error(const char* fmt, ...);
+// device int32 registered with tce_set_range_flag (NULL = check disabled); see include/tce_rvos.h
+int* tce_range_flag();
+#define TCE_RANGE_LIMIT 60000.f
 
 #define TCE_CHECK_ARG(cond, ...)            \
   do {                                      \

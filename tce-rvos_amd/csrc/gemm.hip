@@ -167,12 +167,13 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, cons
 
   // --- epilogue
   const bool vec_ok = tce_epi_vec_ok(C, p.ldc, res, p.ldres, bias, p.res_mode);
+  tce_amax_t amax = 0;  // unused: the exact-fp32 kernel has no operand-range contract
 #define EPI_BODY(ACT, RES)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                \
     const int row = tm * BM + wm * WM + i * 32 + l31;                                                             \
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                \
         tce_epi_store_t<ACT, RES>(acc[i][j], bias, res, C, row, tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N,   \
-                                  p.ldc, p.ldres, vec_ok);                                                        \
+                                  p.ldc, p.ldres, vec_ok, amax);                                                  \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
 #undef EPI_BODY

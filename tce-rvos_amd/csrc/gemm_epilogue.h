@@ -4,6 +4,20 @@
 #pragma once
 #include "common.h"
 
+// Range guard of the split-fp16 arithmetic (include/tce_rvos.h, tce_set_range_flag): running maximum over what an
+// epilogue stores, kept on the BIT PATTERNS of |v| (unsigned compare is monotonic for non-negative floats and ranks
+// Inf / NaN above every finite value, so they trip the limit too): 3 VALU per 2 values.
+typedef unsigned tce_amax_t;
+__device__ __forceinline__ unsigned tce_absbits(const float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
+__device__ __forceinline__ tce_amax_t tce_amax4(tce_amax_t amax, const f32x4 o) {
+  amax = max(amax, max(tce_absbits(o[0]), tce_absbits(o[1])));
+  return max(amax, max(tce_absbits(o[2]), tce_absbits(o[3])));
+}
+__device__ __forceinline__ tce_amax_t tce_amax1(tce_amax_t amax, const float v) { return max(amax, tce_absbits(v)); }
+__device__ __forceinline__ void tce_range_report(int* flag, const tce_amax_t amax) {
+  if (flag && amax >= __builtin_bit_cast(unsigned, TCE_RANGE_LIMIT)) *flag = 1;
+}
+
 template <int ACT, int RES>
 __device__ __forceinline__ void tce_epi_store(const f32x16& x, const float bv, const float* __restrict__ res,
                                               float* __restrict__ C, const int row0, const int col, const int M,
@@ -39,7 +53,7 @@ template <int ACT, int RES>
 __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __restrict__ bias,
                                                 const float* __restrict__ res, float* __restrict__ C, const int row,
                                                 const int n0, const int M, const int N, const long long ldc,
-                                                const long long ldres, const bool vec_ok) {
+                                                const long long ldres, const bool vec_ok, tce_amax_t& amax) {
   if (row >= M) return;
   float* crow = C + (long long)row * ldc;
   const float* rrow = (RES != 0) ? res + (long long)row * ldres : nullptr;
@@ -63,6 +77,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
         if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
         o[c] = v;
       }
+      amax = tce_amax4(amax, o);
       *reinterpret_cast<f32x4*>(crow + n0 + 8 * g) = o;
     }
   } else {
@@ -78,6 +93,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
           if (RES == 1) v += rrow[n];
           if (RES == 2) v *= rrow[n];
           if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
+          amax = tce_amax1(amax, v);
           crow[n] = v;
         }
       }
@@ -95,7 +111,7 @@ __device__ __forceinline__ void tce_epi_store_lds(const f32x16& x, float* __rest
                                                   const float* __restrict__ bias, const float* __restrict__ res,
                                                   float* __restrict__ C, const int row0, const int col0, const int M,
                                                   const int N, const long long ldc, const long long ldres,
-                                                  const bool vec_ok, const int lane) {
+                                                  const bool vec_ok, const int lane, tce_amax_t& amax) {
   const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -142,6 +158,7 @@ __device__ __forceinline__ void tce_epi_store_lds(const f32x16& x, float* __rest
       if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
       o[c] = v;
     }
+    amax = tce_amax4(amax, o);
     if (row < M) {
       if (full) *reinterpret_cast<f32x4*>(C + (long long)row * ldc + n) = o;
       else {

@@ -71,7 +71,7 @@ static __device__ int g_epi_lds = 1;  // tuning aid: 1 = LDS-staged coalesced ep
 // round trip, which is what bounds the small / short-K problems of this path.
 template <int BM, int BN, int WAVES_M, bool CONV, bool HAS_A2, int DEPTH>
 __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
-    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
+    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n, int* const range_flag) {
   constexpr int NT = 128 * WAVES_M;                   // threads: WAVES_M x 2 waves
   constexpr int RP = NT / 8;                          // tile rows covered by one loader pass
   constexpr int WM = BM / WAVES_M, WN = BN / 2;
@@ -265,19 +265,23 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   // measured (tools/gemm_stamps.py): LDS staging pays for the 8-wave 256x128 tile (9.1k -> 7.7k cycles), not for the
   // 4-wave tiles (3.6k -> 5.0k), where direct row-per-lane float4 stores stay
   const bool epi_lds = (WAVES_M == 4) && g_epi_lds != 0;
+  tce_amax_t amax = 0;
 #define EPI_BODY(ACT, RES)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                        \
       if (epi_lds)                                                                                          \
         tce_epi_store_lds<ACT, RES>(acc[i][j], wbuf, bias, res, C, tm * BM + wm * WM + i * 32,              \
-                                    tn * BN + wn * WN + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane);    \
+                                    tn * BN + wn * WN + j * 32, p.M, p.N, p.ldc, p.ldres, vec_ok, lane,     \
+                                    amax);                                                                  \
       else                                                                                                  \
         tce_epi_store_t<ACT, RES>(acc[i][j], bias, res, C, tm * BM + wm * WM + i * 32 + l31,                \
-                                  tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N, p.ldc, p.ldres, vec_ok);  \
+                                  tn * BN + wn * WN + j * 32 + 4 * lhi, p.M, p.N, p.ldc, p.ldres, vec_ok,   \
+                                  amax);                                                                    \
     }                                                                                                       \
   }
   TCE_EPI_DISPATCH(p.act, p.res_mode, EPI_BODY)
 #undef EPI_BODY
+  tce_range_report(range_flag, amax);
   if (stamps) {
     stamps[3] = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,11 +295,11 @@ void launch(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1), block(128 * WAVES_M);
   if (a.conv)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
   else if (a.A2)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
   else
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
 }
 
 

@@ -10,12 +10,22 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ out, int L,
-                                                       int C, float eps) {
+                                                       int C, float eps, int pad_id) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= L) return;
+  long long pid;
+  if (pos_ids) {
+    pid = pos_ids[tok];
+  } else {
+    // HF create_position_ids_from_input_ids: pad + (number of non-pad tokens up to and including this one), pad -> pad
+    int cnt = 0;
+    for (int i = lane; i <= tok; i += 64) cnt += ids[i] != pad_id;
+    cnt = (int)wave_sum((float)cnt);
+    pid = ids[tok] != pad_id ? pad_id + cnt : pad_id;
+  }
   const f32x4* w4 = reinterpret_cast<const f32x4*>(word + ids[tok] * C);
-  const f32x4* p4 = reinterpret_cast<const f32x4*>(pos + pos_ids[tok] * C);
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(pos + pid * C);
   const f32x4* t4 = reinterpret_cast<const f32x4*>(type0);
   const int n4 = C >> 2;
   float s = 0.f;
@@ -117,11 +127,11 @@ __global__ void __launch_bounds__(256) tanh_kernel(const float* __restrict__ x, 
 
 extern "C" int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos,
                                 const float* type0, const float* gamma, const float* beta, float* out, int32_t L,
-                                int32_t C, float eps, tceStream stream) {
-  TCE_CHECK_ARG(ids && pos_ids && word && pos && type0 && gamma && beta && out && L > 0 && C > 0 && C % 4 == 0,
+                                int32_t C, float eps, int32_t pad_id, tceStream stream) {
+  TCE_CHECK_ARG(ids && word && pos && type0 && gamma && beta && out && L > 0 && C > 0 && C % 4 == 0,
                 "tce_embed_ln_f32: bad arguments");
   hipLaunchKernelGGL(embed_ln_kernel, dim3(tce_cdiv(L, 4)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
-                     type0, gamma, beta, out, L, C, eps);
+                     type0, gamma, beta, out, L, C, eps, pad_id);
   TCE_CHECK_LAUNCH("tce_embed_ln_f32");
   return TCE_OK;
 }

@@ -88,11 +88,27 @@ def gather_clip_masks_async(local: torch.Tensor, n_total: int, group=None) -> Pe
     return PendingGather(work, out, counts, padded)
 
 
-def run_sharded(forward_clip, clips: List, n_total: int = None, group=None) -> torch.Tensor:
-    """forward_clip(clip) -> mask tensor [T,Q,h,w]; `clips` is the GLOBAL list (every rank indexes its block)."""
+def run_sharded(forward_clip, clips: List, n_total: int = None, group=None, like: torch.Tensor = None) -> torch.Tensor:
+    """forward_clip(clip) -> per-clip result tensor (mask logits [T,Q,h,w], or the harness's uint8 masks [T,H0,W0]:
+    4x fewer bytes on the wire); `clips` is the GLOBAL list (every rank indexes its block).  A rank whose block is
+    empty (n_total < world) contributes zero clips: it needs the per-clip shape and dtype, taken from `like` (a tensor
+    shaped like one result) or, failing that, learnt from the other ranks through one small object all-gather."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_total = len(clips) if n_total is None else n_total
     lo, hi = shard_range(n_total, rank, world)
-    local = torch.stack([forward_clip(clips[i]) for i in range(lo, hi)], 0)
+    outs = [forward_clip(clips[i]) for i in range(lo, hi)]
+    meta = (tuple(outs[0].shape), outs[0].dtype, str(outs[0].device)) if outs else None
+    if like is not None and meta is None:
+        meta = (tuple(like.shape), like.dtype, str(like.device))
+    if world > 1 and 0 < n_total < world and like is None:  # same condition on every rank: all of them take part
+        metas = [None] * world
+        dist.all_gather_object(metas, meta, group=group)
+        if meta is None:
+            shape, dtype, _ = next(m for m in metas if m is not None)
+            dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+            meta = (shape, dtype, str(dev))
+    if meta is None:
+        raise ValueError("run_sharded: this rank has no clips and no `like` tensor to take the result shape from")
+    local = torch.stack(outs, 0) if outs else torch.empty((0,) + tuple(meta[0]), dtype=meta[1], device=torch.device(meta[2]))
     return gather_clip_masks(local, n_total, group)

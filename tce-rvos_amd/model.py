@@ -55,6 +55,17 @@ def nested_tensor_from_videos_list(videos_list: List[torch.Tensor], size_divisib
     return NestedTensor(vids, masks)
 
 
+# Every hipGraph this process ever instantiated.  Captured clips carry parallel branches (text beside the backbone, decoder
+# beside the pixel decoder); the HIP runtime (ROCm 7.x, libamdhip64 hip::Graph::UpdateStreams) runs them on internal
+# streams that graph executables SHARE, and destroying one executable leaves the others with dangling stream pointers:
+# a later replay of a surviving graph segfaults inside hipGraphLaunch.  So executables are never destroyed while the
+# process lives: an evicted / invalidated cache entry gives back its arenas (gigabytes) and keeps only the (small,
+# never replayed) executable alive here.  The list is bounded by a per-process capture budget: once it is spent,
+# shapes that are not cached run eagerly.
+_ALL_GRAPHS = []
+GRAPH_BUDGET = int(__import__("os").environ.get("TCE_GRAPH_BUDGET", 512))
+
+
 class _Node(nn.Module):
     """Parameter container; carries no computation."""
 
@@ -96,6 +107,9 @@ class ReferFormer(nn.Module):
             raise NotImplementedError("kernels are built for hidden_dim=256, nheads=8 (head_dim 32)")
         if cfg.num_feature_levels != 4:
             raise NotImplementedError("num_feature_levels must be 4")
+        if cfg.enc_n_points != 4 or cfg.dec_n_points != 4:
+            raise NotImplementedError("the fused MSDA launch program is built for enc_n_points = dec_n_points = 4 "
+                                      "(L*P = 16 samples per head); the generic op tce_ms_deform_attn_forward_f32 is not")
         shapes = param_shapes(cfg)
         for key, shape in shapes.items():
             node, leaf = self._node_for(key)
@@ -115,19 +129,31 @@ class ReferFormer(nn.Module):
         if text_encoder is None:
             text_encoder = build_text_encoder(args)
         self.text_encoder = text_encoder
-        self.tokenizer = tokenizer if tokenizer is not None else SyntheticTokenizer()
+        if tokenizer is None:
+            tokenizer = build_tokenizer(args)
+        self.tokenizer = tokenizer
         if args is not None and getattr(args, "freeze_text_encoder", False):
             for p in self.text_encoder.parameters():
                 p.requires_grad_(False)
         self._packed = None
         self._text = None
-        self._arena = None
+        self._arenas = {}  # eager path: one bump arena per slot
         self._shape_cache = {}
-        self._graphs = {}
+        self._text_cache = OrderedDict()
         self.arena_bytes = None  # override to force an arena size
-        # hipGraph replay of the whole per-clip launch program (one graph per input shape); TCE_GRAPH=0 disables
+        # hipGraph replay of the whole per-clip launch program (one graph per input shape); TCE_GRAPH=0 disables.
+        # Every graph owns private arenas (~3 GB at config 2, ~11 GB at config 5), and the callers feed whole videos
+        # of varying length / size / caption length (inference_ytvos.py:278-295), so the cache is an LRU bounded in
+        # entries AND bytes, and a shape is only captured once it comes back (the first `graph_after` sightings run
+        # eagerly: capturing costs an eager warm-up, a device sync and the capture itself).
         import os
         self.use_graph = os.environ.get("TCE_GRAPH", "1") != "0"
+        self._graphs = OrderedDict()
+        self._sightings = OrderedDict()
+        self.max_graphs = int(os.environ.get("TCE_GRAPH_CACHE", 6))
+        self.max_graph_bytes = int(float(os.environ.get("TCE_GRAPH_CACHE_GB", 96)) * 2 ** 30)
+        self.graph_after = int(os.environ.get("TCE_GRAPH_AFTER", 1))
+        self.text_cache_size = int(os.environ.get("TCE_TEXT_CACHE", 0))  # expressions kept (0 = recompute like the reference)
 
     # ---------------------------------------------------------------- parameter tree
     def _node_for(self, key):
@@ -165,7 +191,11 @@ class ReferFormer(nn.Module):
         self._packed = None
         self._text = None
         self._shape_cache = {}
-        self._graphs = {}
+        if getattr(self, "_graphs", None):
+            torch.cuda.synchronize()
+        self._graphs = OrderedDict()
+        self._sightings = OrderedDict()
+        self._text_cache = OrderedDict()
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -192,6 +222,9 @@ class ReferFormer(nn.Module):
                 raise RuntimeError(f"parameter {k} must be a CUDA float32 tensor (model.to('cuda') first); "
                                    f"there is no CPU path")
             w[k] = v.detach()
+        # split-fp16 contract, host half: every GEMM weight inside the fp16 range (activations: ops.range_flag)
+        ops.check_weight_range(w.items())
+        ops.range_flag(next(iter(w.values())).device)
         with torch.no_grad():
             # MSDA: one projection for (sampling offsets | attention logits)
             for k in list(sd):
@@ -308,12 +341,14 @@ class ReferFormer(nn.Module):
         tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
         return self.arena_bytes or int(tok0 * 4 * (2048 * 2.2 + 256 * 24) + (256 << 20))
 
-    def _get_arena(self, T, H0, W0, device):
-        """The eager path's shared arena (captured graphs own a private one each: their addresses are baked in)."""
+    def _get_arena(self, T, H0, W0, device, slot=0):
+        """The eager path's arena of `slot` (captured graphs own a private one each: their addresses are baked in).
+        One arena per slot: forwards kept in flight on different streams must not share activations."""
         need = self._arena_bytes(T, H0, W0)
-        if self._arena is None or self._arena.buf.numel() < need or self._arena.device != torch.device(device):
-            self._arena = ops.Arena(device, need)
-        return self._arena
+        ar = self._arenas.get(slot)
+        if ar is None or ar.buf.numel() < need or ar.device != torch.device(device):
+            ar = self._arenas[slot] = ops.Arena(device, need)
+        return ar
 
     # ---------------------------------------------------------------- the boundary
     @torch.no_grad()
@@ -351,32 +386,78 @@ class ReferFormer(nn.Module):
         frames = vids[0].to(torch.float32).contiguous()
         size = targets[0]["size"]
         img_h, img_w = float(size[0]), float(size[1])
-        ids, att = self._tokenise(captions, frames.device)
+        ids, att, ids_host = self._tokenise(captions, frames.device)
         if self._packed is None:
             self._pack()
+        ops.range_poll(frames.device)  # split-fp16 range guard: a tripped flag of an EARLIER forward raises here
+        cached = self._text_lookup(ids, ids_host)
+        if cached is not None:  # text features of this expression are cached: the clip runs from them
+            out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot)
+        else:
+            key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot))
+            if not self._want_graph(key):
+                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot)
+            else:
+                # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder
+                # beside the pixel decoder
+                ent = self._graphs.get(key)
+                if ent is None:
+                    st = (frames.clone(), ids.clone(), att.clone())
+
+                    def text_fn(alloc):
+                        return self._text_plan().forward(st[1], alloc)
+
+                    ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames)
+                out = self._replay(key, ent, (frames, ids, att))
+        ops.range_snapshot_async(frames.device)
+        return out
+
+    def _want_graph(self, key):
+        """Graph replay for shapes that come back; eager launches for the first `graph_after` sightings of a shape."""
         if not self.use_graph:
-            return self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None)
-        # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder beside
-        # the pixel decoder
-        key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot))
-        ent = self._graphs.get(key)
+            return False
+        if key in self._graphs:
+            return True
+        n = self._sightings.get(key, 0)
+        self._sightings[key] = n + 1
+        self._sightings.move_to_end(key)
+        while len(self._sightings) > 256:
+            self._sightings.popitem(last=False)
+        return n >= self.graph_after and len(_ALL_GRAPHS) < GRAPH_BUDGET
+
+    # ---------------------------------------------------------------- per-expression text cache (SURVEY 8f rank 2)
+    def _text_lookup(self, ids, ids_host=None):
+        """(last_hidden_state [L,768], pooler_output [768]) of a cached expression or None.  The reference recomputes
+        RoBERTa for every clip of an expression (tce_rvos.py:406-424 inside forward; inference_ytvos.py:184-230 loops
+        the clips); with `text_cache_size > 0` the features are computed once per distinct token sequence.  The
+        lookup key is the token ids on the HOST, so the cache is meant for string captions / host id tensors."""
+        if self.text_cache_size <= 0:
+            return None
+        key = tuple(int(v) for v in (ids if ids_host is None else ids_host).reshape(-1).tolist())  # device ids: one sync
+        ent = self._text_cache.get(key)
         if ent is None:
-            st = (frames.clone(), ids.clone(), att.clone())
-
-            def text_fn(alloc):
-                return self._text_plan().forward(st[1], alloc)
-
-            ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames)
-        return self._replay(ent, (frames, ids, att))
+            hid, pooled = self._text_plan().forward(
+                ids, lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ids.device))
+            ent = (hid, pooled)
+            self._text_cache[key] = ent
+            while len(self._text_cache) > self.text_cache_size:
+                self._text_cache.popitem(last=False)
+        else:
+            self._text_cache.move_to_end(key)
+        return ent
 
     def _tokenise(self, captions, device):
         if isinstance(captions, (list, tuple)):
-            ids, att = self.tokenizer(list(captions))  # host tensors
+            if isinstance(self.tokenizer, SyntheticTokenizer):
+                ids, att = self.tokenizer(list(captions))  # host tensors
+            else:  # a HuggingFace tokenizer, called as the reference calls it (tce_rvos.py:408)
+                tok = self.tokenizer.batch_encode_plus(list(captions), padding="longest", return_tensors="pt")
+                ids, att = tok["input_ids"], tok["attention_mask"]
             if bool((att != 1).any()):
                 raise NotImplementedError("padded captions (B > 1) are not supported")
         else:  # token ids: every position is a token (no device read-back here: it would serialise consecutive clips)
             ids, att = captions, torch.ones_like(captions)
-        return ids.to(device), att.to(device)
+        return ids.to(device), att.to(device), (None if ids.is_cuda else ids)
 
     def _text_plan(self):
         """RoBERTa on the HIP kernels (text_encoder.py); the HF module only owns the weights."""
@@ -391,11 +472,11 @@ class ReferFormer(nn.Module):
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
-    def _run(self, frames, text, img_h, img_w, res):
+    def _run(self, frames, text, img_h, img_w, res, slot=0):
         from .pipeline import run_clip
         T, _, H0, W0 = frames.shape
-        if res is None:  # eager: shared arena, single stream
-            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device))
+        if res is None:  # eager: the slot's arena, single stream
+            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot))
         arena, side_arena, side_stream = res
         return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False)
 
@@ -411,8 +492,14 @@ class ReferFormer(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = fn(res)
-        ent = (graph, statics, out, res)
+        _ALL_GRAPHS.append(graph)  # executables outlive their cache entry (see _ALL_GRAPHS)
+        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel())
         self._graphs[key] = ent
+        # LRU bound (entries and bytes); the entry just captured always stays.  Eviction returns the arenas.
+        while len(self._graphs) > 1 and (len(self._graphs) > self.max_graphs or
+                                         sum(e[4] for e in self._graphs.values()) > self.max_graph_bytes):
+            torch.cuda.synchronize()  # the evicted graph may still be replaying
+            self._graphs.popitem(last=False)
         return ent
 
     @staticmethod
@@ -424,9 +511,9 @@ class ReferFormer(nn.Module):
             n += h * w
         return n + ((h + 1) // 2) * ((w + 1) // 2)
 
-    @staticmethod
-    def _replay(ent, inputs):
-        graph, statics, out, _ = ent
+    def _replay(self, key, ent, inputs):
+        self._graphs.move_to_end(key)
+        graph, statics, out = ent[0], ent[1], ent[2]
         for d_, s_ in zip(statics, inputs):
             d_.copy_(s_)
         graph.replay()
@@ -436,25 +523,25 @@ class ReferFormer(nn.Module):
     @torch.no_grad()
     def forward_text_encoder(self, captions, device):
         """tce_rvos.py:406-424 up to the RoBERTa outputs: (last_hidden_state [1,L,768], pooler_output [1,768])."""
-        ids, att = self._tokenise(captions, device)
+        ids, att, _ = self._tokenise(captions, device)
         hid, pooled = self._text_plan().forward(
             ids, lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ids.device))
         return hid[None], pooled[None]
 
     @torch.no_grad()
-    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w):
+    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w, slot=0):
         """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768]."""
         if self._packed is None:
             self._pack()
         text_hidden, text_pooled = text_hidden.contiguous(), text_pooled.contiguous()
-        if not self.use_graph:
-            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None)
-        key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training)
+        key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training, int(slot))
+        if not self._want_graph(key):
+            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot)
         ent = self._graphs.get(key)
         if ent is None:
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
             ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res), frames)
-        return self._replay(ent, (frames, text_hidden, text_pooled))
+        return self._replay(key, ent, (frames, text_hidden, text_pooled))
 
 
 def is_frozen_bn_key(key):
@@ -482,6 +569,23 @@ def build_text_encoder(args=None):
     m = transformers.RobertaModel(cfg)
     torch.random.set_rng_state(st)
     return m.eval()
+
+
+def build_tokenizer(args=None):
+    """The reference builds RobertaTokenizerFast.from_pretrained('roberta-base') (tce_rvos.py:136, a download).  With
+    `args.text_encoder_path` (a local copy of the checkpoint) the real tokenizer is loaded from the same directory --
+    real weights with hashed ids would give wrong masks silently, so a failure to load it is an error.  Without a
+    path the text weights are random anyway and a deterministic hashing stand-in keeps string captions usable."""
+    path = getattr(args, "text_encoder_path", None) if args is not None else None
+    if not path:
+        return SyntheticTokenizer()
+    import transformers
+    try:
+        return transformers.RobertaTokenizerFast.from_pretrained(path)
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(f"text_encoder_path={path!r}: the RoBERTa weights load from there but the tokenizer files "
+                           f"(vocab.json / merges.txt / tokenizer.json) do not ({e}); pass tokenizer=... explicitly or "
+                           f"call the model with token ids") from e
 
 
 class _Stub(nn.Module):

@@ -84,6 +84,77 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Operand-range guard of the split-fp16 arithmetic (include/tce_rvos.h: tce_set_range_flag).  fp16 saturates at
+# 65504: weights are checked on the host when they are packed (check_weight_range), activations where they are
+# produced -- every split-mode GEMM / fused-FFN epilogue raises a sticky device flag when it stores |v| >= 60000,
+# Inf or NaN.  Reading the flag needs a host sync, so the model reads it at ITS sync points (one clip late in
+# steady state); check_range() reads it now.
+# ---------------------------------------------------------------------------------------------------------------
+FP16_RANGE_LIMIT = 60000.0
+_RANGE = {}
+
+
+class RangeError(RuntimeError):
+    pass
+
+
+def range_flag(device=None):
+    """The device flag (int32[1]) registered with the library; created (and registered) on first use."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _RANGE.get(dev)
+    if st is None:
+        st = {"flag": torch.zeros(1, dtype=torch.int32, device=dev), "host": torch.zeros(1, dtype=torch.int32).pin_memory(),
+              "event": None}
+        _RANGE[dev] = st
+    check(lib().tce_set_range_flag(st["flag"].data_ptr()), "tce_set_range_flag")
+    return st
+
+
+def range_snapshot_async(device=None):
+    """Queues a 4-byte copy of the flag to pinned host memory on the current stream (no host sync)."""
+    st = range_flag(device)
+    st["host"].copy_(st["flag"], non_blocking=True)
+    st["event"] = torch.cuda.Event()
+    st["event"].record()
+
+
+def range_poll(device=None, wait=False):
+    """Raises RangeError if a completed snapshot shows the flag set.  wait=True blocks on the pending snapshot."""
+    st = range_flag(device)
+    ev = st["event"]
+    if ev is None:
+        return
+    if wait:
+        ev.synchronize()
+    elif not ev.query():
+        return
+    st["event"] = None
+    if int(st["host"][0]) != 0:
+        st["flag"].zero_()
+        st["host"].zero_()
+        raise RangeError("an activation left the fp16 range of the split-fp16 GEMM arithmetic (|x| >= 60000, Inf or NaN) in a "
+                         "previous launch: its results are invalid.  Run with ops.set_gemm_mode('f32') (exact fp32 MFMA).")
+
+
+def check_range(device=None):
+    """Synchronous form: snapshot the flag now, wait, raise RangeError if any launch so far tripped it."""
+    range_snapshot_async(device)
+    range_poll(device, wait=True)
+
+
+def check_weight_range(named_tensors):
+    """Host-side half of the guard, run when operands are packed: every GEMM weight must lie inside the fp16 range."""
+    bad = []
+    for name, t in named_tensors:
+        if t.is_floating_point() and t.numel() and not bool(t.abs().max() < FP16_RANGE_LIMIT):
+            bad.append(name)
+    if bad and get_gemm_mode() == "f16x3":
+        raise RangeError(f"parameters outside the fp16 range of the split-fp16 GEMM arithmetic (|w| >= {FP16_RANGE_LIMIT:g} or "
+                         f"non-finite): {bad[:5]}{'...' if len(bad) > 5 else ''}.  Select the exact fp32 kernels with "
+                         f"ops.set_gemm_mode('f32') before loading these weights.")
+
+
 def _chk(t, name):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise TypeError(f"{name}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
@@ -471,6 +542,15 @@ def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_
     ldo = out.stride(0) if out.dim() == 2 else Cn
     gi, bi = (ln_in[0].data_ptr(), ln_in[1].data_ptr()) if ln_in is not None else (None, None)
     go, bo = (ln_out[0].data_ptr(), ln_out[1].data_ptr()) if ln_out is not None else (None, None)
-    check(lib().tce_ffn_fused_f32(x.data_ptr(), ldx, packed.data_ptr(), b2.data_ptr(), gi, bi, eps_in, go, bo, eps_out,
-                                  out.data_ptr(), ldo, M, Cn, Hd, act, _stream()), "tce_ffn_fused_f32")
+    def go_():
+        check(lib().tce_ffn_fused_f32(x.data_ptr(), ldx, packed.data_ptr(), b2.data_ptr(), gi, bi, eps_in, go, bo, eps_out,
+                                      out.data_ptr(), ldo, M, Cn, Hd, act, _stream()), "tce_ffn_fused_f32")
+    if GEMM_PROFILE is None:
+        go_()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go_()
+    e1.record()
+    GEMM_PROFILE.append((f"ffn_fused_kernel<{Cn}", False, 4.0 * M * Cn * Hd, e0, e1))
     return out

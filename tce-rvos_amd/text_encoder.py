@@ -41,14 +41,13 @@ class TextPlan:
         """ids int64 [1, L] on the GPU; A = arena allocator.  Returns (last_hidden_state [L,C], pooler_output [C])."""
         sd, C, L = self.sd, self.C, ids.shape[1]
         s = ops._stream()
-        mask = ids.ne(self.pad).to(torch.int64)
-        pos_ids = (torch.cumsum(mask, dim=1) * mask + self.pad).contiguous()  # create_position_ids_from_input_ids
         x = A(L, C)
-        check(lib().tce_embed_ln_f32(ids.data_ptr(), pos_ids.data_ptr(), sd["embeddings.word_embeddings.weight"].data_ptr(),
+        # position ids (HF create_position_ids_from_input_ids) are derived inside the kernel: no ATen arithmetic here
+        check(lib().tce_embed_ln_f32(ids.data_ptr(), None, sd["embeddings.word_embeddings.weight"].data_ptr(),
                                      sd["embeddings.position_embeddings.weight"].data_ptr(),
                                      sd["embeddings.token_type_embeddings.weight"].data_ptr(),
                                      sd["embeddings.LayerNorm.weight"].data_ptr(), sd["embeddings.LayerNorm.bias"].data_ptr(),
-                                     x.data_ptr(), L, C, self.eps, s), "tce_embed_ln_f32")
+                                     x.data_ptr(), L, C, self.eps, self.pad, s), "tce_embed_ln_f32")
         qkv, att, hdn = A(L, 3 * C), A(L, C), A(L, self.ff)
         # M = L (32 tokens) against 768..3072-deep weights: split K so that ~200 workgroups stream each weight matrix
         # instead of N/64 (ops.splitk_for); the partial sums meet in `ws`

@@ -52,7 +52,7 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [8, 5])
+@pytest.mark.parametrize("n_total", [8, 5, 1])   # 1: rank 1's block is empty (n_total < world)
 def test_clip_sharding_and_gather_world2(n_total):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -45,6 +45,11 @@ def _compare(out, fx, atol_mask, prefix="out_"):
     print("max abs diffs vs reference:", res)
     assert res["pred_logits"] < 2e-3 and res["pred_boxes"] < 1e-4 and res["reference_points"] < 1e-4
     assert res["pred_masks"] < atol_mask
+    # relative form of the same bound: the synthetic weights give mask logits of magnitude 1e2..1e3, where an absolute
+    # tolerance says little -- require |d| <= 2e-5 * max|ref| as well (fp32 round-off through ~60 layers is ~3e-6)
+    scale = float(np.abs(fx[prefix + "pred_masks"]).max())
+    print("pred_masks max|ref| %.1f -> relative error %.2e" % (scale, res["pred_masks"] / scale))
+    assert res["pred_masks"] <= 2e-5 * scale
     a = out["pred_masks"].cpu()[0] > 0
     b = torch.from_numpy(fx[prefix + "pred_masks"])[0] > 0
     iou = O.mask_iou(a, b)
@@ -167,8 +172,10 @@ def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
         ref = O.forward(sd, cfg, frames, hid[None], pooled[None], img_size=(H, W))
     diffs = {k: (out[k].cpu() - ref[k]).abs().max().item() for k in ("pred_logits", "pred_boxes", "pred_masks")}
     iou = O.mask_iou(out["pred_masks"].cpu() > 0, ref["pred_masks"] > 0)
-    print(backbone, "max abs diffs vs oracle:", diffs, "IoU", iou)
+    scale = ref["pred_masks"].abs().max().item()
+    print(backbone, "max abs diffs vs oracle:", diffs, "IoU", iou, "mask logit scale", scale)
     assert diffs["pred_logits"] < 5e-3 and diffs["pred_boxes"] < 2e-4 and diffs["pred_masks"] < 5e-2
+    assert diffs["pred_masks"] <= 5e-5 * scale   # relative bound (oracle and HIP path both carry fp32 round-off here)
     assert iou > 1 - 1e-3
 
 
@@ -225,3 +232,121 @@ def test_text_encoder_hip_matches_huggingface(layers, L):
     d2 = (pooled - enc.pooler_output[0]).abs().max().item()
     print("text encoder max abs diff: hidden", d1, "pooled", d2)
     assert d1 < 2e-4 and d2 < 1e-4
+
+
+def test_unit_scale_mask_logits_make_the_iou_criterion_bite(models):
+    """The default synthetic weights give mask logits of magnitude ~1e2, so almost no pixel sits near the threshold
+    and `IoU > 1 - 1e-3` would survive large errors.  Here the controller's last layer is scaled so that the dynamic
+    mask head produces logits of O(1) (a realistic, trained-like regime): a visible share of pixels lies within 1e-2
+    of the threshold, and the 1e-3 IoU criterion of the north star has to be earned."""
+    model = models("swin_t_p4w7", 21)
+    with torch.no_grad():
+        for k in ("controller.layers.2.weight", "controller.layers.2.bias"):
+            model.state_dict(keep_vars=True)[k].mul_(0.2)   # the mask MLP is cubic in its generated parameters
+    model.repack()
+    T, H, W = 5, 180, 320
+    frames = synth_frames(T, H, W, 31)
+    g = torch.Generator().manual_seed(8)
+    hid, pooled = torch.randn(20, 768, generator=g), torch.tanh(torch.randn(768, generator=g))
+    out = model.forward_features(frames.cuda(), hid.cuda(), pooled.cuda(), float(H), float(W))
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    with torch.no_grad():
+        ref = O.forward(sd, O.OracleConfig(), frames, hid[None], pooled[None], img_size=(H, W))
+    rm = ref["pred_masks"]
+    near = (rm.abs() < 1e-2).float().mean().item()
+    d = (out["pred_masks"].cpu() - rm).abs().max().item()
+    iou = O.mask_iou(out["pred_masks"].cpu() > 0, rm > 0)
+    print(f"mask logits: mean|x| {rm.abs().mean():.3f} std {rm.std():.3f}; {100 * near:.2f} % of pixels within 1e-2 of the "
+          f"threshold; max|d| {d:.2e}; IoU {iou:.6f}")
+    assert 0.05 < rm.abs().mean().item() < 20.0, "salt no longer gives O(1) logits"
+    assert near > 1e-3, "too few pixels near the threshold for the IoU criterion to discriminate"
+    assert d <= 2e-5 * max(1.0, rm.abs().max().item()) + 2e-5
+    assert iou > 1 - 1e-3
+    load = __import__("tce_rvos_amd", fromlist=["load_synth_weights"]).load_synth_weights
+    load(model, 21)   # leave the shared model as other tests expect it
+    model.repack()
+
+
+def test_graph_cache_is_bounded_lru_over_many_shapes(models):
+    """The callers feed whole videos of varying length and caption length: 20 distinct (T, L) shapes must not pile up
+    graphs / arenas.  Shapes run eagerly on first sight, are captured when they come back, and the
+    cache holds at most `max_graphs` entries."""
+    model = models("swin_t_p4w7", 3)
+    model.max_graphs, model.graph_after = 3, 1
+    H, W = 64, 96
+    tgt = [{"size": torch.tensor([H, W])}]
+    shapes = [(1 + i % 5, 5 + i // 5) for i in range(20)]
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    outs = {}
+    for rnd in range(3):   # round 0 eager, round 1 capture + replay, round 2 replay or re-capture after eviction
+        for (T, L) in shapes:
+            ids = torch.arange(3, 3 + L)[None]
+            o = model([synth_frames(T, H, W, T).cuda()], ids, tgt)["pred_masks"]
+            if rnd == 0:
+                outs[(T, L)] = o.clone()
+            else:
+                assert torch.equal(o, outs[(T, L)]), "eager and graph-replay results differ"
+            assert len(model._graphs) <= 3
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_allocated() - base
+    per_graph = max(e[4] for e in model._graphs.values())
+    assert grown <= 4 * per_graph + (1 << 30), f"memory grew by {grown / 2**30:.1f} GiB over 60 forwards"
+    model.max_graphs, model.graph_after = 6, 1
+
+
+def test_text_cache_and_video_driver(models):
+    """run_video() = the DAVIS clip_size chunking (inference_davis.py:209-256) / whole-video clips
+    (inference_ytvos.py:278-295) over the forward + harness kernels, with RoBERTa evaluated once per expression."""
+    from tce_rvos_amd.video import run_video
+    model = models("swin_t_p4w7", 5)
+    N, H, W, H0, W0 = 11, 64, 96, 120, 180
+    frames = synth_frames(N, H, W, 17).cuda()
+    ids = torch.randint(3, 50000, (1, 9), generator=torch.Generator().manual_seed(2))
+    ids[0, 0], ids[0, -1] = 0, 2
+    tgt = [{"size": torch.tensor([H, W])}]
+    model.text_cache_size = 0
+    ref_chunks = []
+    for lo in range(0, N, 4):   # the caller's loop written out: one forward per chunk, harness on the oracle side
+        o = model([frames[lo:lo + 4]], ids, tgt)
+        m, q = O.select_masks(o["pred_logits"].cpu()[0], o["pred_masks"].cpu()[0], (H0, W0))
+        ref_chunks.append((m, q))
+    model.text_cache_size = 4
+    res = run_video(model, frames, ids, (H0, W0), clip_size=4)
+    assert len(model._text_cache) == 1
+    assert tuple(res["masks"].shape) == (N, H0, W0) and res["masks"].dtype == torch.uint8
+    got = res["masks"].cpu().bool()
+    want = torch.cat([m for m, _ in ref_chunks], 0)
+    assert [int(v) for v in res["best_query"].cpu()] == [int(q) for _, q in ref_chunks]
+    assert O.mask_iou(got, want) > 1 - 1e-3
+    # cached text features == recomputed ones, bit for bit (same kernels, same inputs)
+    a = model([frames[:4]], ids, tgt)["pred_masks"]
+    model.text_cache_size = 0
+    b = model([frames[:4]], ids, tgt)["pred_masks"]
+    assert torch.equal(a, b)
+    whole = run_video(model, frames, ids, (H0, W0), clip_size=None)   # YTVOS style: the video is one clip
+    assert tuple(whole["masks"].shape) == (N, H0, W0) and whole["best_query"].numel() == 1
+
+
+def test_run_sharded_world1_on_gpu(models):
+    """dist.run_sharded with real clips through the HIP forward (world = 1: the gather is the identity), moving the
+    harness's uint8 masks instead of fp32 logits."""
+    from tce_rvos_amd import ops
+    from tce_rvos_amd.dist import run_sharded
+    model = models("swin_t_p4w7", 9)
+    H, W = 64, 96
+    tgt = [{"size": torch.tensor([H, W])}]
+    ids = torch.arange(3, 12)[None]
+    clips = [synth_frames(3, H, W, 40 + i).cuda() for i in range(8)]
+
+    def fwd(clip):
+        o = model([clip], ids, tgt)
+        return ops.select_masks(o["pred_logits"][0], o["pred_masks"][0], (H, W))[0]
+
+    out = run_sharded(fwd, clips)
+    assert tuple(out.shape) == (8, 3, H, W) and out.dtype == torch.uint8
+    for i in (0, 7):
+        assert torch.equal(out[i], fwd(clips[i]))
+    empty = run_sharded(fwd, [], like=out[0])
+    assert tuple(empty.shape) == (0, 3, H, W)

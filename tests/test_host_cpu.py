@@ -23,8 +23,12 @@ def test_header_symbols_all_exported_and_bound(built_lib):
     declared = set(re.findall(r"\b(tce_[a-z0-9_]+)\s*\(", hdr))
     from tce_rvos_amd import _lib
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    dbg = open(os.path.join(ROOT, "include", "tce_rvos_debug.h")).read()
+    declared_dbg = set(re.findall(r"\b(tce_[a-z0-9_]+)\s*\(", dbg))
+    assert declared_dbg == set(_lib.DEBUG_SIGNATURES), (declared_dbg ^ set(_lib.DEBUG_SIGNATURES))
+    assert not (declared & declared_dbg)
     l = ctypes.CDLL(built_lib)
-    for name in declared:
+    for name in declared | declared_dbg:
         assert hasattr(l, name), name
     assert _lib.lib().tce_abi_version() == 1
 

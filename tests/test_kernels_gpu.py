@@ -375,29 +375,6 @@ def test_harness_select_masks_matches_reference_caller(ops):
         assert O.mask_iou(m.cpu().bool(), ref) > 1 - 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 384, 96), (2049, 130, 256)])
-def test_gemm_presplit_dma_prototype(ops, M, N, K):
-    """tce_split_f16_f32 + tce_gemm_h2_f32 (pre-split operands, LDS-DMA ring): same arithmetic as the shipped split GEMM."""
-    from tce_rvos_amd._lib import lib, check
-    g = torch.Generator().manual_seed(M)
-    a, pos = torch.randn(M, K, generator=g), torch.randn(100, K, generator=g)
-    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
-    da, dpos, dw, db = dev(a), dev(pos), dev(w), dev(b)
-    planes = [torch.empty(M, K, dtype=torch.float16, device="cuda") for _ in range(2)] + \
-             [torch.empty(N, K, dtype=torch.float16, device="cuda") for _ in range(2)]
-    check(lib().tce_split_f16_f32(da.data_ptr(), dpos.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), M, K, 100,
-                                  ops._stream()), "split A")
-    check(lib().tce_split_f16_f32(dw.data_ptr(), None, planes[2].data_ptr(), planes[3].data_ptr(), N, K, 0, ops._stream()),
-          "split W")
-    a_eff = a + pos[torch.arange(M) % 100]
-    rec = planes[0].float().cpu() + planes[1].float().cpu()
-    assert (rec - a_eff).abs().max().item() < 2e-6 * a_eff.abs().max().item() + 1e-7
-    out = torch.empty(M, N, device="cuda")
-    check(lib().tce_gemm_h2_f32(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(),
-                                db.data_ptr(), None, out.data_ptr(), M, N, K, K, K, N, 0, 2, 0, 0, ops._stream()), "h2")
-    close(out, F.gelu(F.linear(a_eff, w, b)), 1e-4, 1e-4)
-
-
 @pytest.mark.parametrize("T,H,W", [(1, 72, 100), (2, 37, 61), (1, 360, 640)])
 def test_resnet_stem_and_maxpool(ops, T, H, W):
     """conv 7x7/s2/p3 + folded frozen BN + ReLU, then MaxPool2d(3, 2, 1), vs PyTorch on the CPU (oracle ops)."""
@@ -566,3 +543,42 @@ def test_ffn_fused_rejects_bad_arguments(ops):
     x = dev(torch.zeros(10, 96))
     with pytest.raises(TceError):
         ops.ffn_fused(x, pk, dev(torch.zeros(96)), 64, 0)   # no activation code 0
+
+
+def test_split_fp16_range_guard(ops):
+    """The split-fp16 GEMM's operand contract (|x| inside the fp16 range) is guarded: weights on the host when they are
+    packed, activations by the sticky device flag every split-mode epilogue raises when it stores |v| >= 60000 / Inf /
+    NaN.  Tiny operands are not an error: the documented absolute floor (6e-8 per factor) must hold."""
+    from tce_rvos_amd.ops import RangeError
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 256, 256
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    ops.check_range()                                   # clean start
+    ops.gemm(dev(a), dev(w))
+    ops.check_range()                                   # in-range problem: no flag
+    out = ops.gemm(dev(a * 1e5), dev(w))                # result ~1e5: outside the range the NEXT GEMM could consume
+    with pytest.raises(RangeError):
+        ops.check_range()
+    ops.check_range()                                   # the flag is cleared by the raise
+    nan = a.clone()
+    nan[7, 3] = float("nan")
+    ops.gemm(dev(nan), dev(w))
+    with pytest.raises(RangeError):
+        ops.check_range()
+    with pytest.raises(RangeError):                     # host half: weights beyond the range are refused at pack time
+        ops.check_weight_range([("w", dev(w * 1e6))])
+    ops.check_weight_range([("w", dev(w))])
+    # tiny operands: absolute error within K * 6e-8 * max|w| * (a few) of the fp64 result -- never silently large
+    tiny = a * 1e-6
+    out = ops.gemm(dev(tiny), dev(w)).cpu().double()
+    ref = tiny.double() @ w.double().T
+    assert (out - ref).abs().max().item() <= 4 * 6e-8 * w.abs().max().item() * math.sqrt(K)
+    ops.check_range()
+    # the fused FFN raises the flag for an out-of-range hidden value as well
+    C, Hd = 256, 64
+    w1, w2 = torch.randn(Hd, C, generator=g), torch.randn(C, Hd, generator=g) / 8
+    pk = ops.ffn_pack(dev(w1), dev(torch.zeros(Hd)), dev(w2))
+    x = dev(torch.randn(200, C, generator=g) * 1e4)
+    ops.ffn_fused(x, pk, dev(torch.zeros(C)), Hd, ops.ACT_RELU, out=torch.empty_like(x))
+    with pytest.raises(RangeError):
+        ops.check_range()
