@@ -76,7 +76,7 @@ int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const 
                       int64_t M, int32_t C, float eps, tceStream stream);
 
 /* GroupNorm on channels-last x[T, HW, C] with G groups of C/G consecutive channels, optional ReLU.
- * ws: device workspace of at least T*G*nsplit*3 floats (nsplit = tce_groupnorm_nsplit(HW)).
+ * ws: device workspace of at least T*G*(nsplit*3 + 2) floats (nsplit = tce_groupnorm_nsplit(HW)).
  * Reference: nn.GroupNorm(32, 256) tce_rvos.py:81,86; nn.GroupNorm(8, C) segmentation.py:43. */
 int tce_groupnorm_nsplit(int32_t HW);
 int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,

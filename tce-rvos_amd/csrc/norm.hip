@@ -355,12 +355,92 @@ __global__ void __launch_bounds__(256) groupnorm_stats_kernel(const float* __res
   }
 }
 
+// Single-pass form for C = 256 (every GroupNorm of the path: tce_rvos.py:81,86 with 32 groups, segmentation.py:43 with 8):
+// a wave reads one full 1 KiB row per instruction (64 lanes x 16 B, lane = 4 consecutive channels, all of one group),
+// a workgroup keeps its 4 x R rows in registers, so the chunk's mean and its M2 about that mean (the same two-pass
+// arithmetic as above) cost ONE trip to HBM; 4 x R float4 loads are in flight per lane.
+template <int R>
+__global__ void __launch_bounds__(256) groupnorm_stats_rows_kernel(const float* __restrict__ x, float* __restrict__ ws,
+                                                                   const int HW, const int G, const int rows_per,
+                                                                   const int nsplit) {
+  __shared__ float red[4][64];
+  const int t = blockIdx.y, sp = blockIdx.x;
+  const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lpg = 64 / G;  // lanes per group: 2 (32 groups) or 8 (8 groups)
+  const float* base = x + (long long)t * HW * 256 + lane * 4;
+  f32x4 v[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int row = r0 + wave + 4 * i;
+    v[i] = *reinterpret_cast<const f32x4*>(base + (long long)min(row, HW - 1) * 256);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (r0 + wave + 4 * i < r1) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  for (int o = 1; o < lpg; o <<= 1) s += __shfl_xor(s, o, 64);
+  red[wave][lane] = s;
+  __syncthreads();
+  const float n = (float)((r1 - r0) * (256 / G));
+  const float mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / n;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (r0 + wave + 4 * i < r1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  for (int o = 1; o < lpg; o <<= 1) q += __shfl_xor(q, o, 64);
+  red[wave][lane] = q;
+  __syncthreads();
+  if (wave == 0 && (lane % lpg) == 0) {
+    const int g = lane / lpg;
+    float* o = ws + ((long long)(t * G + g) * nsplit + sp) * 3;
+    o[0] = n;
+    o[1] = mean;
+    o[2] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
+}
+
+// merges the nsplit partial (count, mean, M2) triples of a (frame, group) with Chan's formula -> (mean, rstd).
+// One wave per (frame, group): lanes take partials lane, lane + 64, ... (their loads are independent L2 round trips: a
+// serial walk over ~100 partials would cost more than the statistics pass), then a 6-step butterfly merges the lanes.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, const float nb, const float mb, const float m2b) {
+  const float nt = n + nb;
+  if (nt > 0.f) {
+    const float d = mb - mean, f = nb / nt;
+    mean += d * f;
+    m2 += m2b + d * d * (n * f);
+  }
+  n = nt;
+}
+__global__ void __launch_bounds__(64) groupnorm_finalize_kernel(const float* __restrict__ ws, float* __restrict__ fin,
+                                                                const int nsplit, const float eps) {
+  const int tg = blockIdx.x, lane = threadIdx.x;
+  const float* p = ws + (long long)tg * nsplit * 3;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int i = lane; i < nsplit; i += 64) chan_merge(n, mean, m2, p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+    chan_merge(n, mean, m2, nb, mb, m2b);
+  }
+  if (lane == 0) {
+    fin[2 * tg] = mean;
+    fin[2 * tg + 1] = rsqrtf(m2 / n + eps);
+  }
+}
+
 __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ ws,
+                                                              const float* __restrict__ fin,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                              int HW, int C, int G, int nsplit, float eps, int relu,
-                                                              int rows_per_block) {
+                                                              int HW, int C, int G, int relu, int rows_per_block) {
   extern __shared__ float sm[];  // scale[C], shift[C]
   float* scale = sm;
   float* shift = sm + C;
@@ -368,18 +448,7 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __res
   const int cg = C / G;
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cg;
-    const float* p = ws + ((long long)(t * G + g) * nsplit) * 3;
-    float n = p[0], mean = p[1], m2 = p[2];
-    for (int i = 1; i < nsplit; ++i) {
-      const float nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
-      if (nb > 0.f) {
-        const float nt = n + nb, d = mb - mean;
-        mean += d * (nb / nt);
-        m2 += m2b + d * d * (n * nb / nt);
-        n = nt;
-      }
-    }
-    const float rstd = rsqrtf(m2 / n + eps);
+    const float mean = fin[2 * (t * G + g)], rstd = fin[2 * (t * G + g) + 1];
     const float sc = rstd * gamma[c];
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
@@ -473,25 +542,29 @@ extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const fl
   return TCE_OK;
 }
 
-extern "C" int tce_groupnorm_nsplit(int32_t HW) {
-  int n = HW / 512;
-  if (n < 1) n = 1;
-  if (n > 32) n = 32;
-  return n;
-}
+static int groupnorm_rows_per(int HW) { return HW >= 4096 ? 128 : (HW >= 512 ? 32 : 8); }
+extern "C" int tce_groupnorm_nsplit(int32_t HW) { return tce_cdiv(HW, groupnorm_rows_per(HW)); }
 
 extern "C" int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
                                  int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream) {
   TCE_CHECK_ARG(x && gamma && beta && out && ws, "tce_groupnorm_f32: null pointer");
   TCE_CHECK_ARG(T > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0, "tce_groupnorm_f32: bad shape");
   TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out), "tce_groupnorm_f32: x/out must be 16-byte aligned");
-  const int nsplit = tce_groupnorm_nsplit(HW);
+  const int rows_per = groupnorm_rows_per(HW), nsplit = tce_cdiv(HW, rows_per);
+  float* fin = ws + (long long)T * G * nsplit * 3;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(T * G, nsplit), dim3(256), 0, s, x, ws, HW, C, G, nsplit);
+  if (C == 256 && (G == 8 || G == 16 || G == 32 || G == 64)) {
+    const dim3 grid(nsplit, T);
+    if (rows_per == 128) hipLaunchKernelGGL(groupnorm_stats_rows_kernel<32>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+    else if (rows_per == 32) hipLaunchKernelGGL(groupnorm_stats_rows_kernel<8>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+    else hipLaunchKernelGGL(groupnorm_stats_rows_kernel<2>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+  } else {
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(T * G, nsplit), dim3(256), 0, s, x, ws, HW, C, G, nsplit);
+  }
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(T * G), dim3(64), 0, s, ws, fin, nsplit, eps);
   const int rows_per_block = 64;
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(tce_cdiv(HW, rows_per_block), T), dim3(256),
-                     (size_t)2 * C * sizeof(float), s, x, ws, gamma, beta, out, HW, C, G, nsplit, eps, relu,
-                     rows_per_block);
+                     (size_t)2 * C * sizeof(float), s, x, fin, gamma, beta, out, HW, C, G, relu, rows_per_block);
   TCE_CHECK_LAUNCH("tce_groupnorm_f32");
   return TCE_OK;
 }

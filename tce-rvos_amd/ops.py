@@ -269,7 +269,7 @@ def groupnorm_cl(x, gamma, beta, T, HW, Cn, G, eps=1e-5, relu=False, out=None, w
     _chk(x, "x")
     nsplit = lib().tce_groupnorm_nsplit(HW)
     if ws is None:
-        ws = alloc(T * G * nsplit * 3) if alloc else torch.empty(T * G * nsplit * 3, dtype=torch.float32, device=x.device)
+        ws = alloc(T * G * (nsplit * 3 + 2)) if alloc else torch.empty(T * G * (nsplit * 3 + 2), dtype=torch.float32, device=x.device)
     if out is None:
         out = alloc(T * HW, Cn) if alloc else torch.empty(T * HW, Cn, dtype=torch.float32, device=x.device)
     check(lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW,

@@ -132,7 +132,9 @@ def test_layernorm(ops, M, C):
     close(ops.layernorm(dev(x), dev(ga), dev(be), r=dev(r), eps=1e-12), F.layer_norm(x + r, (C,), ga, be, 1e-12), 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("T,HW,C,G,relu", [(2, 60, 256, 32, False), (3, 1300, 256, 8, True), (1, 14400, 64, 8, True)])
+@pytest.mark.parametrize("T,HW,C,G,relu", [(2, 60, 256, 32, False), (3, 1300, 256, 8, True), (1, 14400, 64, 8, True),
+                                           (5, 14400, 256, 8, True), (2, 4097, 256, 32, False), (1, 513, 256, 64, False),
+                                           (1, 7, 256, 16, True)])
 def test_groupnorm(ops, T, HW, C, G, relu):
     g = torch.Generator().manual_seed(HW)
     x = torch.randn(T, HW, C, generator=g) * 2 + 0.5
