@@ -23,6 +23,15 @@ class GemmArgs(C.Structure):
                 ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32)]
 
 
+class RowLinArgs(C.Structure):
+    _fields_ = [("x", c_f), ("a2", c_f), ("packed", c_f), ("bias", c_f), ("res", c_f), ("out", c_f),
+                ("g_in", c_f), ("be_in", c_f), ("g_out", c_f), ("be_out", c_f),
+                ("ldx", i64), ("lda2", i64), ("ldres", i64), ("ldo", i64),
+                ("sX", i64), ("sA2", i64), ("sRes", i64), ("sOut", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("batch", i32), ("a2_rows", i32), ("act", i32), ("res_mode", i32),
+                ("eps_in", f32), ("eps_out", f32)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol of include/tce_rvos.h (tests check this)
 SIGNATURES = {
     "tce_abi_version": (i32, []),
@@ -64,6 +73,9 @@ SIGNATURES = {
     "tce_ffn_packed_bytes": (i64, [i32, i32]),
     "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tce_ffn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f]),
+    "tce_rowlin_packed_bytes": (i64, [i32, i32]),
+    "tce_rowlin_pack_f32": (i32, [c_f, i64, c_f, i32, i32, c_f]),
+    "tce_rowlin_f32": (i32, [C.POINTER(RowLinArgs), c_f]),
     "tce_graph_begin": (i32, [c_f]),
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),

@@ -80,6 +80,209 @@ __device__ __forceinline__ HL split8(const float* v) {
   return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-wave staging tile in LDS: 32 rows x 32 floats, 144-byte pitch.  Global memory is touched only in full 128-byte
+// lines (one instruction = 8 rows x 128 B: lane l -> row 8i + (l>>3), 16-byte piece l&7), the MFMA side reads / writes
+// row-per-lane; with the 144-byte pitch both patterns are bank-conflict free.  A wave's LDS operations execute in
+// order, so its private tile needs no workgroup barrier -- only the compiler must not reorder (wave_barrier).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WT_PITCH = 36;                 // floats
+constexpr int WT_BYTES = 32 * WT_PITCH * 4;  // 4608 bytes per wave
+
+// x[32 tokens, K] (+ a2, LayerNorm) -> fp16 hi/lo B fragments (lane (r, hf) holds k = 16s + 8hf + 0..7 of token r).
+// a2: optional addend with row pitch lda2; a2_rows > 0: its row index is (token % a2_rows) (a position map shared by
+// all frames).  g_in / be_in: optional LayerNorm over K applied to (x + a2).
+template <int K>
+__device__ __forceinline__ void load_x_frags(const float* __restrict__ x, const long long ldx,
+                                             const float* __restrict__ a2, const long long lda2, const int a2_rows,
+                                             const int m0, const int M, float* __restrict__ wt, const int lane,
+                                             const float* __restrict__ g_in, const float* __restrict__ be_in,
+                                             const float eps, h16x8 (&xh)[K / 16], h16x8 (&xl)[K / 16]) {
+  constexpr int NP = K / 32;
+  const int cr = lane >> 3, cp = (lane & 7) * 4;
+  const int r = lane & 31, hf = lane >> 5;
+  f32x4 v[NP][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + 8 * i + cr, M - 1);
+    const float* px = x + (long long)row * ldx + cp;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v[q][i] = *reinterpret_cast<const f32x4*>(px + 32 * q);
+    if (a2) {
+      const float* pa = a2 + (long long)(a2_rows > 0 ? row % a2_rows : row) * lda2 + cp;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) v[q][i] += *reinterpret_cast<const f32x4*>(pa + 32 * q);
+    }
+  }
+  if (g_in) {
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) sum += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      mean[i] = sum * (1.f / K);
+      float sq = 0.f;
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[q][i][e] - mean[i];
+          sq = fmaf(d, d, sq);
+        }
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 4, 64);
+      rstd[i] = rsqrtf(sq * (1.f / K) + eps);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(g_in + 32 * q + cp);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(be_in + 32 * q + cp);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][i][e] = (v[q][i][e] - mean[i]) * rstd[i] * g[e] + b[e];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wt + (8 * i + cr) * WT_PITCH + cp) = v[q][i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* pr = wt + r * WT_PITCH + 16 * h + 8 * hf;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pr);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pr + 4);
+      const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      const HL sp = split8(f);
+      xh[2 * q + h] = sp.hi;
+      xl[2 * q + h] = sp.lo;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// residual tile res[32 tokens, col0 .. col0+31] as four full-line loads per lane (issue them for ALL tiles first: a
+// load -> LDS -> registers chain per tile would pay one memory round trip per tile)
+struct ResTile {
+  f32x4 v[4];
+};
+__device__ __forceinline__ ResTile tile_res_load(const float* __restrict__ res, const long long ldres, const int m0,
+                                                 const int M, const int col0, const int lane) {
+  const int cr = lane >> 3, cp = (lane & 7) * 4;
+  ResTile t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + 8 * i + cr, M - 1);
+    t.v[i] = *reinterpret_cast<const f32x4*>(res + (long long)row * ldres + col0 + cp);
+  }
+  return t;
+}
+
+// bias[col0 .. col0+31] in accumulator order (4 x float4 per lane); loaded ahead of use like the residual tile
+struct BiasTile {
+  f32x4 v[4];
+};
+__device__ __forceinline__ BiasTile tile_bias_load(const float* __restrict__ bias, const int col0, const int lane) {
+  BiasTile b;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    b.v[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) b.v[g] = *reinterpret_cast<const f32x4*>(bias + col0 + 8 * g + 4 * (lane >> 5));
+  }
+  return b;
+}
+
+// acc (32 channels col0.. of 32 tokens, lane = token) = (acc + bias tile) (+ / *) residual tile
+template <int RES>  // 0 none, 1 add, 2 multiply
+__device__ __forceinline__ void tile_bias_res(f32x16& acc, const BiasTile& bt, const ResTile& rt,
+                                              float* __restrict__ wt, const int lane) {
+  const int cr = lane >> 3, cp = (lane & 7) * 4;
+  const int r = lane & 31, hf = lane >> 5;
+  if (RES != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wt + (8 * i + cr) * WT_PITCH + cp) = rt.v[i];
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 bv = bt.v[g];
+    if (RES != 0) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(wt + r * WT_PITCH + 8 * g + 4 * hf);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (RES == 1) acc[4 * g + c] = acc[4 * g + c] + bv[c] + rv[c];
+        else acc[4 * g + c] = (acc[4 * g + c] + bv[c]) * rv[c];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * g + c] += bv[c];
+    }
+  }
+  if (RES != 0) __builtin_amdgcn_wave_barrier();
+}
+
+// stores acc (32 channels of 32 tokens) in full 128-byte lines
+__device__ __forceinline__ void tile_store(const f32x16& acc, float* __restrict__ out, const long long ldo, const int m0,
+                                           const int M, const int col0, float* __restrict__ wt, const int lane,
+                                           tce_amax_t& amax) {
+  const int cr = lane >> 3, cp = (lane & 7) * 4;
+  const int r = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    amax = tce_amax4(amax, o);
+    *reinterpret_cast<f32x4*>(wt + r * WT_PITCH + 8 * g + 4 * hf) = o;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + 8 * i + cr;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(wt + (8 * i + cr) * WT_PITCH + cp);
+    if (row < M) *reinterpret_cast<f32x4*>(out + (long long)row * ldo + col0 + cp) = o;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// LayerNorm over the N = 32 * NT channels a lane pair (l, l^32) holds in acc[NT] (registers 4g..4g+3 of tile t =
+// channels 32t + 8g + 4hf + 0..3)
+template <int NT>
+__device__ __forceinline__ void rows_layernorm(f32x16 (&acc)[NT], const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, const float eps, const int hf) {
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += acc[t][i];
+  sum += __shfl_xor(sum, 32, 64);
+  const float mean = sum * (1.f / (32 * NT));
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float d = acc[t][i] - mean;
+      sq = fmaf(d, d, sq);
+    }
+  sq += __shfl_xor(sq, 32, 64);
+  const float rstd = rsqrtf(sq * (1.f / (32 * NT)) + eps);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + 32 * t + 8 * g + 4 * hf);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + 32 * t + 8 * g + 4 * hf);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = (acc[t][4 * g + c] - mean) * rstd * gv[c] + bv[c];
+    }
+}
+
 struct FfnArgs {
   const float* x;
   const unsigned char* wpk;
@@ -100,14 +303,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   constexpr int STAGE = P * PIECE;
   constexpr int STEPS = KS + 2 * NT;
   static_assert(SLOTS <= STEPS, "more DMA slots than loop steps");
-  static_assert(2 * STAGE <= 160 * 1024, "ring does not fit the LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];  // the ONLY LDS object: base offset 0
+  static_assert(2 * STAGE + WAVES * WT_BYTES <= 160 * 1024, "ring + staging tiles do not fit the LDS");
+  // the ONLY LDS object (base offset 0): two ring stages, then one staging tile per wave
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + WAVES * WT_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hf = lane >> 5;
-  const int m = blockIdx.x * (32 * WAVES) + wave * 32 + r;
-  const int mc = min(m, p.M - 1);
+  const int hf = lane >> 5;
 
   // The ring is written only by DMA (inline asm), which the compiler cannot see: without a visible store it treats
   // every read of `smem` as undefined and deletes it.  This store never executes (NI >= 2 always).
@@ -131,59 +333,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) dma(0, q);
 
-  // ---- x: 32 tokens x C, B-fragment order (lane (r, hf) holds k = 16s + 8hf + 0..7 of token r), optional LayerNorm
+  // ---- x: 32 tokens x C -> fp16 hi/lo B fragments, full-line loads staged through this wave's private tile
+  const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
+  float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  {
-    float xf[KS][8];
-    const float* px = p.x + (long long)mc * p.ldx + 8 * hf;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(px + 16 * s);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(px + 16 * s + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xf[s][j] = a[j];
-        xf[s][4 + j] = b[j];
-      }
-    }
-    if (p.g_in) {
-      float sum = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += xf[s][j];
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.f / C);
-      float sq = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float d = xf[s][j] - mean;
-          sq += d * d;
-        }
-      sq += __shfl_xor(sq, 32, 64);
-      const float rstd = rsqrtf(sq * (1.f / C) + p.eps_in);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_in + 16 * s + 8 * hf);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.g_in + 16 * s + 8 * hf + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.be_in + 16 * s + 8 * hf);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.be_in + 16 * s + 8 * hf + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          xf[s][j] = (xf[s][j] - mean) * rstd * g0[j] + b0[j];
-          xf[s][4 + j] = (xf[s][4 + j] - mean) * rstd * g1[j] + b1[j];
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const HL f = split8(xf[s]);
-      xh[s] = f.hi;
-      xl[s] = f.lo;
-    }
-  }
+  load_x_frags<C>(p.x, p.ldx, nullptr, 0, 0, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl);
 
   f32x16 oacc[NT];
 #pragma unroll
@@ -290,58 +444,18 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   }
   if (stamps) stamps[2] = (long long)__builtin_amdgcn_s_memtime();
 
-  // ---- epilogue: lane = token, accumulator registers 4g..4g+3 of tile t = channels 32t + 8g + 4hf + (0..3)
-  const float* xr = p.x + (long long)mc * p.ldx + 4 * hf;
+  // ---- epilogue: + b2 + residual, optional LayerNorm, stores -- all global traffic in full lines through the wave's
+  // staging tile
+  {
+    ResTile rt[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(p.x, p.ldx, m0, p.M, 32 * t, lane);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + 32 * t + 8 * g + 4 * hf);
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + 32 * t + 8 * g);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[t][4 * g + c] += bv[c] + rv[c];
-    }
-  if (p.g_out) {
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sum += oacc[t][i];
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.f / C);
-    float sq = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float d = oacc[t][i] - mean;
-        sq += d * d;
-      }
-    sq += __shfl_xor(sq, 32, 64);
-    const float rstd = rsqrtf(sq * (1.f / C) + p.eps_out);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(p.g_out + 32 * t + 8 * g + 4 * hf);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.be_out + 32 * t + 8 * g + 4 * hf);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) oacc[t][4 * g + c] = (oacc[t][4 * g + c] - mean) * rstd * gv[c] + bv[c];
-      }
+    for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
   }
-  if (m < p.M) {
-    float* po = p.out + (long long)m * p.ldo + 4 * hf;
+  if (p.g_out) rows_layernorm<NT>(oacc, p.g_out, p.be_out, p.eps_out, hf);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = oacc[t][4 * g + c];
-        amax = tce_amax4(amax, o);
-        *reinterpret_cast<f32x4*>(po + 32 * t + 8 * g) = o;
-      }
-  }
+  for (int t = 0; t < NT; ++t) tile_store(oacc[t], p.out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
   tce_range_report(p.range_flag, amax);
   if (stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,6 +509,248 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
     o = __builtin_bit_cast(u32x4, plane ? f.lo : f.hi);
   }
   reinterpret_cast<u32x4*>(out)[u] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Token-stationary linear layer ("rowlin"):  out[M,N] = LN_out?( epi( LN_in?(x + a2) W^T + bias ) )   K = 96..256
+// Same machinery as the fused FFN: x (32 tokens per wave, K/2 registers) is loaded once in full lines and stays in
+// registers as fp16 hi/lo B fragments; W [N,K] is pre-split / pre-ordered into 1 KiB A fragments, one block of
+// 2*K/16 pieces per 32 output channels, streamed L2 -> LDS by DMA through a two-stage ring; each 32-channel
+// accumulator tile is finished (bias, activation, residual add / multiply) and stored in full lines through the
+// wave's staging tile while the next tile's weights are in flight.  ROW mode (N = 256) keeps all 8 tiles in registers
+// and applies a LayerNorm over the row before storing: out_proj + residual + LayerNorm of the post-norm transformer
+// blocks in one launch.  Replaces the K <= 256 nn.Linear / 1x1 conv call sites with many rows
+// (tce_deformable_transformer.py:439-489,535-548; ops/modules/ms_deform_attn.py:94-101,115; segmentation.py:187,330-372;
+// swin_transformer.py:133,151; tce_rvos.py:260).
+// ---------------------------------------------------------------------------------------------------------------
+struct LinArgs {
+  const float *x, *a2;
+  const unsigned char* wpk;
+  const float *bias, *res;
+  float* out;
+  const float *g_in, *be_in, *g_out, *be_out;
+  long long ldx, lda2, ldres, ldo;
+  long long sX, sA2, sRes, sOut;  // batch strides in floats (grid.y)
+  int M, N, a2_rows, act, res_mode;
+  float eps_in, eps_out;
+  int* range_flag;
+};
+
+template <int K, bool ROW>
+__global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs p) {
+  // The ring holds HALF blocks (the first / second K/32 k-steps of a 32-channel tile, hi and lo pieces interleaved,
+  // padded to a multiple of 4 pieces so that every wave issues the same number of DMAs): three half-stages, the DMA of
+  // half h+2 is issued while half h is multiplied.  3 x 16 KiB + staging tiles = 66 KiB at K = 256: two workgroups
+  // per CU in streaming mode (<= 256 registers), so one workgroup's tile epilogue hides under the other's MFMAs.
+  constexpr int WAVES = 4, KS = K / 16, KH = KS / 2;
+  constexpr int HP = (2 * KH + WAVES - 1) / WAVES * WAVES;  // pieces per half block
+  constexpr int SLOTS = HP / WAVES;
+  constexpr int HSTAGE = HP * PIECE;
+  constexpr int NTR = 8;  // ROW mode: N = 256
+  static_assert(KS % 2 == 0 && SLOTS <= KH, "piece count");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * HSTAGE + WAVES * WT_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hf = lane >> 5;
+  const int bz = blockIdx.y;
+  const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
+  if (p.M < 0) reinterpret_cast<u32x4*>(smem)[tid] = u32x4{0u, 0u, 0u, 0u};  // see ffn_fused_kernel
+
+  const float* const x = p.x + bz * p.sX;
+  const float* const a2 = p.a2 ? p.a2 + bz * p.sA2 : nullptr;
+  const float* const res = p.res ? p.res + bz * p.sRes : nullptr;
+  float* const out = p.out + bz * p.sOut;
+  // streaming mode: the 32-channel tiles may be split over gridDim.z workgroups (each re-reads x: a few MB against a
+  // much shorter serial chain of tiles per workgroup, which is what bounds launches with few rows)
+  const int ntiles = p.N / 32;
+  const int t_begin = ROW ? 0 : (int)((long long)blockIdx.z * ntiles / gridDim.z);
+  const int t_end = ROW ? ntiles : (int)((long long)(blockIdx.z + 1) * ntiles / gridDim.z);
+
+  long long* const stamps = (g_ffn_stamps && blockIdx.x < 1024 && bz == 0 && blockIdx.z == 0 && tid == 0) ? g_ffn_stamps + blockIdx.x * 8 : nullptr;
+  if (stamps) {
+    stamps[0] = (long long)__builtin_amdgcn_s_memtime();
+    stamps[4] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned char* wp = p.wpk + ((long long)2 * t_begin * HP + wave) * PIECE;
+  const unsigned voff = lane * 16;
+  const unsigned wbase = wave * PIECE;
+  int dstage = 0;  // ring slot the next half block goes to
+  auto dma_half = [&](int q) { glds16(wp + (long long)q * WAVES * PIECE, voff, wbase + (unsigned)(dstage * HSTAGE + q * WAVES * PIECE)); };
+  auto dma_next = [&]() {
+    wp += HP * PIECE;
+    dstage = dstage == 2 ? 0 : dstage + 1;
+  };
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) dma_half(q);
+    dma_next();
+  }
+
+  float* const wt = reinterpret_cast<float*>(smem + 3 * HSTAGE + wave * WT_BYTES);
+  h16x8 xh[KS], xl[KS];
+  load_x_frags<K>(x, p.ldx, a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl);
+  tce_amax_t amax = 0;
+  if (stamps) stamps[6] = (long long)__builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stamps) stamps[1] = (long long)__builtin_amdgcn_s_memtime();
+
+  int cstage = 0;  // ring slot of the half block being multiplied
+  // one half of a 32-channel tile: acc += W[tile, k-steps of this half] x^T; issues the DMA of the half after next.
+  // Fragments are fetched TWO k-steps ahead of their MFMAs (LDS latency under load is longer than one step's three
+  // MFMAs); sched_barrier pins each step, otherwise the compiler sinks the reads behind the MFMAs they should overlap.
+  auto half_mma = [&](auto half_c, f32x16& acc) {
+    constexpr int S0 = decltype(half_c)::value * KH;
+    const unsigned char* const st = smem + cstage * HSTAGE + lane * 16;
+    h16x8 fh[3], fl[3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < KH) {
+        fh[q] = *reinterpret_cast<const h16x8*>(st + (2 * q) * PIECE);
+        fl[q] = *reinterpret_cast<const h16x8*>(st + (2 * q + 1) * PIECE);
+      }
+#pragma unroll
+    for (int s = 0; s < KH; ++s) {
+      if (s + 2 < KH) {
+        fh[(s + 2) % 3] = *reinterpret_cast<const h16x8*>(st + (2 * s + 4) * PIECE);
+        fl[(s + 2) % 3] = *reinterpret_cast<const h16x8*>(st + (2 * s + 5) * PIECE);
+      }
+      if (s < SLOTS) dma_half(s);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s % 3], xl[S0 + s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s % 3], xh[S0 + s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s % 3], xh[S0 + s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dma_next();
+    cstage = cstage == 2 ? 0 : cstage + 1;
+  };
+  auto act_tile = [&](f32x16& acc) {
+    if (p.act == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.5f * acc[i] * (1.f + erff(acc[i] * 0.70710678118654752440f));
+    }
+  };
+  // bias, activation, residual (activation sits between bias and residual, as in tce_gemm_f32)
+  auto finish_tile = [&](f32x16& acc, const BiasTile& bt, const ResTile& rt) {
+    const ResTile none = {};
+    const BiasTile nob = {};
+    if (p.res_mode == 0 || p.act != 0) {
+      tile_bias_res<0>(acc, bt, none, wt, lane);
+      act_tile(acc);
+      if (p.res_mode == 1) tile_bias_res<1>(acc, nob, rt, wt, lane);
+      else if (p.res_mode == 2) tile_bias_res<2>(acc, nob, rt, wt, lane);
+    } else if (p.res_mode == 1) {
+      tile_bias_res<1>(acc, bt, rt, wt, lane);
+    } else {
+      tile_bias_res<2>(acc, bt, rt, wt, lane);
+    }
+  };
+  // the half just multiplied may be overwritten and the next one must have landed: this wave's DMAs of the half after
+  // next (SLOTS of them) plus `younger` later operations (a tile's 4 stores) may stay in flight
+  auto tile_mma = [&](f32x16& acc, const bool stores_follow) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    half_mma(std::integral_constant<int, 0>{}, acc);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+    __syncthreads();
+    half_mma(std::integral_constant<int, 1>{}, acc);
+    (void)stores_follow;
+  };
+
+  if (ROW) {
+    f32x16 oacc[NTR];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      tile_mma(oacc[t], false);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+      __syncthreads();
+    }
+    {
+      ResTile rt[NTR];
+      if (p.res_mode != 0) {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) rt[t] = tile_res_load(res, p.ldres, m0, p.M, 32 * t, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) finish_tile(oacc[t], tile_bias_load(p.bias, 32 * t, lane), rt[t]);
+    }
+    if (p.g_out) rows_layernorm<NTR>(oacc, p.g_out, p.be_out, p.eps_out, hf);
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) tile_store(oacc[t], out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
+  } else {
+    for (int t = t_begin; t < t_end; ++t) {
+      ResTile rt = {};
+      if (p.res_mode != 0) rt = tile_res_load(res, p.ldres, m0, p.M, 32 * t, lane);  // both land under the MFMAs
+      const BiasTile bt = tile_bias_load(p.bias, 32 * t, lane);
+      f32x16 acc;
+      tile_mma(acc, true);
+      finish_tile(acc, bt, rt);
+      tile_store(acc, out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
+      // older than this tile's 4 stores: the DMAs of the half after next (may fly on) and everything that must be done
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS + 4) : "memory");
+      __syncthreads();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+  tce_range_report(p.range_flag, amax);
+  if (stamps) {
+    stamps[2] = (long long)__builtin_amdgcn_s_memtime();
+    stamps[3] = (long long)__builtin_amdgcn_s_memtime();
+    stamps[5] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// W [N, K] (row pitch ldw) -> per 32 output channels two HALF blocks of HP pieces (HP = 2 * K/32 rounded up to a
+// multiple of 4): piece 2j (+1) of half h = hi (lo) fragment of k-step s = h*K/32 + j: lane (r, hf) holds
+// W[32t + r][16s + 8hf + 0..7]; padding pieces are zero.  Two trailing half blocks of zeros (the prefetch runs two
+// halves ahead).
+__global__ void __launch_bounds__(256) rowlin_pack_kernel(const float* __restrict__ W, unsigned char* __restrict__ out,
+                                                          const int N, const int K, const long long ldw,
+                                                          const long long units) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int KH = K / 32, HP = (2 * KH + 3) / 4 * 4;
+  const int lane = (int)(u & 63);
+  const long long pg = u >> 6;
+  const int piece = (int)(pg % HP);
+  const long long hb = pg / HP;  // half-block index = 2 * tile + half
+  const int t = (int)(hb >> 1), h = (int)(hb & 1);
+  const int r = lane & 31, hf = lane >> 5, s = h * KH + (piece >> 1);
+  u32x4 o = {0u, 0u, 0u, 0u};
+  const int n = 32 * t + r;
+  if (piece < 2 * KH && n < N) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = W[(long long)n * ldw + 16 * s + 8 * hf + j];
+    const HL f = split8(v);
+    o = __builtin_bit_cast(u32x4, (piece & 1) ? f.lo : f.hi);
+  }
+  reinterpret_cast<u32x4*>(out)[u] = o;
+}
+
+inline bool rowlin_shape_ok(int N, int K) { return (K == 96 || K == 128 || K == 192 || K == 256) && N > 0 && N % 32 == 0; }
+inline long long rowlin_units(int N, int K) {
+  const int HP = (2 * (K / 32) + 3) / 4 * 4;
+  return (long long)(2 * (N / 32) + 2) * HP * 64;
+}
+
+template <int K>
+void rowlin_launch(const LinArgs& a, int batch, bool row, hipStream_t s) {
+  // aim at >= ~3 workgroups per CU-pair slot: split the output tiles when the row blocks alone leave the chip idle
+  const int rb = tce_cdiv(a.M, 128) * batch, ntiles = a.N / 32;
+  int nz = 1;
+  if (!row) {
+    while (nz < ntiles && rb * nz < 160 && ntiles / (nz * 2) >= 2) nz *= 2;  // only launches with few row blocks
+  }
+  const dim3 grid(tce_cdiv(a.M, 128), batch, nz), block(256);
+  if (row) hipLaunchKernelGGL((rowlin_kernel<K, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((rowlin_kernel<K, false>), grid, block, 0, s, a);
 }
 
 inline bool ffn_shape_ok(int C, int Hd) { return (C == 96 || C == 128 || C == 192 || C == 256) && Hd > 0 && Hd % 32 == 0; }
@@ -455,5 +811,53 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   else if (C == 128) ffn_launch<128, 8>(a, act, s);
   else ffn_launch<96, 8>(a, act, s);
   TCE_CHECK_LAUNCH("tce_ffn_fused_f32");
+  return TCE_OK;
+}
+
+extern "C" int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K) { return rowlin_shape_ok(N, K) ? rowlin_units(N, K) * 16 : -1; }
+
+extern "C" int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream) {
+  TCE_CHECK_ARG(rowlin_shape_ok(N, K), "tce_rowlin_pack_f32: unsupported shape N=%d K=%d (K in 96/128/192/256, N %% 32 == 0)", N, K);
+  TCE_CHECK_ARG(W && packed && tce_aligned16(packed) && ldw >= K, "tce_rowlin_pack_f32: null / misaligned pointer or ldw < K");
+  const long long units = rowlin_units(N, K);
+  hipLaunchKernelGGL(rowlin_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W,
+                     (unsigned char*)packed, N, K, (long long)ldw, units);
+  TCE_CHECK_LAUNCH("tce_rowlin_pack_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
+  TCE_CHECK_ARG(args != nullptr, "tce_rowlin_f32: null args");
+  const tceRowLinArgs& q = *args;
+  TCE_CHECK_ARG(rowlin_shape_ok(q.N, q.K), "tce_rowlin_f32: unsupported shape N=%d K=%d", q.N, q.K);
+  TCE_CHECK_ARG(q.M > 0 && q.x && q.packed && q.out, "tce_rowlin_f32: null pointer or M <= 0");
+  TCE_CHECK_ARG(q.act >= 0 && q.act <= 2 && q.res_mode >= 0 && q.res_mode <= 2, "tce_rowlin_f32: bad act / res_mode");
+  TCE_CHECK_ARG(q.res_mode == 0 || q.res, "tce_rowlin_f32: res_mode set without res");
+  TCE_CHECK_ARG(q.ldx >= q.K && q.ldx % 4 == 0 && q.ldo >= q.N && q.ldo % 4 == 0 && (!q.res || (q.ldres >= q.N && q.ldres % 4 == 0)) &&
+                    (!q.a2 || (q.lda2 >= q.K && q.lda2 % 4 == 0)),
+                "tce_rowlin_f32: bad row pitch");
+  TCE_CHECK_ARG(q.sX % 4 == 0 && q.sA2 % 4 == 0 && q.sRes % 4 == 0 && q.sOut % 4 == 0, "tce_rowlin_f32: batch strides must be multiples of 4 floats");
+  TCE_CHECK_ARG(tce_aligned16(q.x) && tce_aligned16(q.out) && tce_aligned16(q.packed) && (!q.a2 || tce_aligned16(q.a2)) &&
+                    (!q.res || tce_aligned16(q.res)) && (!q.bias || tce_aligned16(q.bias)),
+                "tce_rowlin_f32: pointers must be 16-byte aligned");
+  TCE_CHECK_ARG((!q.g_in || (q.be_in && tce_aligned16(q.g_in) && tce_aligned16(q.be_in))) &&
+                    (!q.g_out || (q.be_out && tce_aligned16(q.g_out) && tce_aligned16(q.be_out))),
+                "tce_rowlin_f32: LayerNorm gamma/beta must come in pairs, 16-byte aligned");
+  TCE_CHECK_ARG(!q.g_out || q.N == 256, "tce_rowlin_f32: the output LayerNorm is built for N = 256");
+  LinArgs a;
+  a.x = q.x; a.a2 = q.a2; a.wpk = (const unsigned char*)q.packed; a.bias = q.bias; a.res = q.res; a.out = q.out;
+  a.g_in = q.g_in; a.be_in = q.be_in; a.g_out = q.g_out; a.be_out = q.be_out;
+  a.ldx = q.ldx; a.lda2 = q.lda2; a.ldres = q.ldres; a.ldo = q.ldo;
+  a.sX = q.sX; a.sA2 = q.sA2; a.sRes = q.sRes; a.sOut = q.sOut;
+  a.M = q.M; a.N = q.N; a.a2_rows = q.a2_rows; a.act = q.act; a.res_mode = q.res_mode;
+  a.eps_in = q.eps_in; a.eps_out = q.eps_out; a.range_flag = tce_range_flag();
+  const int batch = q.batch > 0 ? q.batch : 1;
+  const bool row = q.g_out != nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (q.K == 256) rowlin_launch<256>(a, batch, row, s);
+  else if (q.K == 192) rowlin_launch<192>(a, batch, row, s);
+  else if (q.K == 128) rowlin_launch<128>(a, batch, row, s);
+  else rowlin_launch<96>(a, batch, row, s);
+  TCE_CHECK_LAUNCH("tce_rowlin_f32");
   return TCE_OK;
 }

@@ -250,6 +250,13 @@ class ReferFormer(nn.Module):
                         w1, w2 = sd[k].detach(), sd[pre + l2].detach()
                         if w1.dim() == 2 and ops.ffn_supported(w1.shape[1], w1.shape[0]):
                             w[pre + tag] = ops.ffn_pack(w1, sd[pre + l1[:-len("weight")] + "bias"].detach(), w2)
+            # token-stationary linear kernel (csrc/chain.hip): packed copies of every eligible weight, registered by
+            # address so ops.gemm_ex can route the shapes where it wins
+            ops.ROWLIN_TABLE.clear()
+            for k in list(w):
+                t = w[k]
+                if torch.is_tensor(t) and t.dtype == torch.float32 and t.dim() == 2 and (k.endswith("weight") or k.endswith(".w")):
+                    ops.rowlin_register(t)
             if cfg.is_resnet:
                 self._pack_resnet(sd, w)
             if cfg.video:

@@ -457,6 +457,11 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
     """Fully explicit form: tensors only provide base pointers (slices / views welcome); all sizes and
     strides (in floats) are given by the caller.  Used by the model for frame-batched launches where the
     addend (a positional map) is shared by all frames (sA2 = 0) or the output is a level slice of [T,S,C]."""
+    if ROWLIN_TABLE and splitk <= 1 and sW == 0 and sBias == 0 and act in (ACT_NONE, ACT_RELU, ACT_GELU):
+        pk = _rowlin_route(w, M, N, K, ldw, batch)
+        if pk is not None:
+            return rowlin(a, pk, out, M, N, K, lda, ldc, bias=bias, a2=a2, lda2=lda2, act=act, res=res, ldres=ldres,
+                          res_mode=res_mode, batch=batch, sX=sA, sA2=sA2, sRes=sRes, sOut=sC)
     g = GemmArgs()
     g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     g.M, g.N, g.K = M, N, K
@@ -471,6 +476,24 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
     g.sA, g.sA2, g.sW, g.sBias, g.sC, g.sRes = sA, sA2, sW, sBias, sC, sRes
     _gemm_launch(g, splitk, ws)
     return out
+
+
+def _rowlin_route(w, M, N, K, ldw, batch):
+    """Packed copy of a registered weight when the token-stationary kernel measured faster than the tiled GEMM for this
+    shape (tools/rowlin_bench.py): K = 96 / 128 with many rows (Swin stage 1, the stride-4 adapter), and K = 192 / 256
+    with N >= 384 (the 384-wide offset/weight projection, the 512-wide q|k projection)."""
+    if K not in ROWLIN_K or N % 32 or get_gemm_mode() != "f16x3":
+        return None
+    rows = M * max(1, batch)
+    if rows < ROWLIN_MIN_ROWS or M < 2048:
+        return None
+    if not (K <= 128 and rows >= 32768) and not (K >= 192 and N >= 384 and N != 576):
+        return None
+    return ROWLIN_TABLE.get((w.data_ptr(), N, K, ldw))
+
+
+def rowlin_lookup(w, N, K, ldw=None):
+    return ROWLIN_TABLE.get((w.data_ptr(), N, K, K if ldw is None else ldw)) if get_gemm_mode() == "f16x3" else None
 
 
 # Opt-in (TCE_SPLITK=1).  Measured at config 2: the skinny GEMMs live in the graph's side branches (text encoder
@@ -553,4 +576,70 @@ def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_
     go_()
     e1.record()
     GEMM_PROFILE.append((f"ffn_fused_kernel<{Cn}", False, 4.0 * M * Cn * Hd, e0, e1))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Token-stationary linear layers (csrc/chain.hip: tce_rowlin_f32).  Weights are packed once; the model registers the
+# packed copies of ITS weights here at pack time (keyed by address + shape) and gemm_ex routes eligible launches to
+# the rowlin kernel.  Only registered weights are routed: a key can never go stale under a caller's temporary tensors.
+# ---------------------------------------------------------------------------------------------------------------
+ROWLIN_TABLE = {}
+ROWLIN_MIN_ROWS = int(os.environ.get("TCE_ROWLIN_MIN_ROWS", 12000))
+ROWLIN_K = (96, 128, 192, 256)
+
+
+def rowlin_pack(w, N=None, K=None, ldw=None):
+    _chk(w, "w")
+    N = w.shape[0] if N is None else N
+    K = w.shape[1] if K is None else K
+    ldw = w.stride(0) if ldw is None else ldw
+    nbytes = lib().tce_rowlin_packed_bytes(N, K)
+    if nbytes < 0:
+        raise ValueError(f"rowlin_pack: unsupported shape N={N} K={K}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib().tce_rowlin_pack_f32(w.data_ptr(), ldw, out.data_ptr(), N, K, _stream()), "tce_rowlin_pack_f32")
+    return out
+
+
+def rowlin_register(w):
+    """Packs a model-owned weight [N, K] (row-strided views welcome) and registers it for routing; no-op if ineligible."""
+    if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] not in ROWLIN_K or w.shape[0] % 32 or not w.is_cuda:
+        return None
+    key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0))
+    if key not in ROWLIN_TABLE:
+        ROWLIN_TABLE[key] = rowlin_pack(w)
+    return ROWLIN_TABLE[key]
+
+
+def rowlin(x, pk, out, M, N, K, ldx, ldo, bias=None, a2=None, lda2=0, a2_rows=0, act=ACT_NONE, res=None, ldres=0,
+           res_mode=RES_NONE, ln_in=None, ln_out=None, eps_in=1e-5, eps_out=1e-5, batch=1, sX=0, sA2=0, sRes=0, sOut=0):
+    from ._lib import RowLinArgs
+    q = RowLinArgs()
+    q.x, q.packed, q.out = x.data_ptr(), pk.data_ptr(), out.data_ptr()
+    q.M, q.N, q.K, q.batch = M, N, K, batch
+    q.ldx, q.ldo = ldx, ldo
+    if a2 is not None:
+        q.a2, q.lda2, q.a2_rows = a2.data_ptr(), lda2, a2_rows
+    if bias is not None:
+        q.bias = bias.data_ptr()
+    if res_mode != RES_NONE:
+        q.res, q.ldres = res.data_ptr(), ldres
+    if ln_in is not None:
+        q.g_in, q.be_in = ln_in[0].data_ptr(), ln_in[1].data_ptr()
+    if ln_out is not None:
+        q.g_out, q.be_out = ln_out[0].data_ptr(), ln_out[1].data_ptr()
+    q.act, q.res_mode, q.eps_in, q.eps_out = act, res_mode, eps_in, eps_out
+    q.sX, q.sA2, q.sRes, q.sOut = sX, sA2, sRes, sOut
+
+    def go():
+        check(lib().tce_rowlin_f32(C.byref(q), _stream()), "tce_rowlin_f32")
+    if GEMM_PROFILE is None:
+        go()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    GEMM_PROFILE.append((f"rowlin_kernel<{K}", False, 2.0 * M * N * K * batch, e0, e1))
     return out

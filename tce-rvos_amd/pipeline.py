@@ -18,6 +18,17 @@ NH = 8
 FFN_FUSED_MIN_ROWS = int(__import__("os").environ.get("TCE_FFN_FUSED_MIN_ROWS", 16000))
 
 
+def _proj_res_ln(x, wt, bias, resid, M, norm_w, norm_b):
+    """resid <- LayerNorm(resid + x W^T + bias)  (N = K = 256).  Many rows: one token-stationary launch (csrc/chain.hip, ROW
+    mode) instead of GEMM + LayerNorm; otherwise the two launches."""
+    pk = ops.rowlin_lookup(wt, D, D) if M >= FFN_FUSED_MIN_ROWS else None
+    if pk is not None:
+        ops.rowlin(x, pk, resid, M, D, D, D, D, bias=bias, res=resid, ldres=D, res_mode=RES_ADD, ln_out=(norm_w, norm_b))
+        return
+    gemm_ex(x, wt, resid, M, D, D, D, D, D, bias=bias, res=resid, ldres=D, res_mode=RES_ADD)
+    ops.layernorm(resid, norm_w, norm_b, 1e-5, out=resid)
+
+
 def _lin(A, x, M, K, w, b, N, **kw):
     out = A(M, N)
     gemm_ex(x, w, out, M, N, K, K, K, N, bias=b, **kw)
@@ -171,8 +182,8 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             ln_(x, norm)
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
-             ar=ar):
-        """resid <- resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src))).  query [T*q_per_frame, D]."""
+             ar=ar, norm=None):
+        """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D]."""
         A = ar.alloc
         m1 = ar.mark()
         value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
@@ -185,8 +196,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                     a2=q_pos, lda2=D)
         samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
                               out=A(q_rows, D))
-        gemm_ex(samp, w[pre + "output_proj.weight"], resid, q_rows, D, D, D, D, D, bias=w[pre + "output_proj.bias"],
-                res=resid, ldres=D, res_mode=RES_ADD)
+        if norm:
+            _proj_res_ln(samp, w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, q_rows,
+                         w[norm + ".weight"], w[norm + ".bias"])
+        else:
+            gemm_ex(samp, w[pre + "output_proj.weight"], resid, q_rows, D, D, D, D, D, bias=w[pre + "output_proj.bias"],
+                    res=resid, ldres=D, res_mode=RES_ADD)
         ar.release(m1)
 
     for i in range(cfg.enc_layers):
@@ -197,8 +212,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             # (1) tokens gather from their frame by MSDA (:447-454)
             r = _lin(A, token, T * Fk, D, w[fp + "reference_points.weight"], w[fp + "reference_points.bias"], 2)
             ref = ops.sigmoid(r, out=A(T * Fk, 2))
-            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, ref, 2, True, token)
-            ln_(token, fp + "norm1")
+            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, ref, 2, True, token, norm=fp + "norm1")
             # (2) all T*F tokens attend to each other (:463-469)
             pre = fp + "token_self_atten."
             qk = A(T * Fk, 2 * D)
@@ -221,14 +235,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(T * S, D)
             ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
-            gemm_ex(att, w[pre + "out_proj.weight"], src, T * S, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=src,
-                    ldres=D, res_mode=RES_ADD)
-            ln_(src, fp + "norm3")
+            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
+                         w[fp + "norm3.bias"])
             ar.release(m0)
             # (4) FFN over all pixels (:489-491)
             ffn(src, T * S, fp, norm=fp + "norm4")
-        msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src)
-        ln_(src, lp + "norm1")
+        msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1")
         ffn(src, T * S, lp, norm=lp + "norm2")
     memory = src
 
@@ -264,8 +276,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                     ldres=D, res_mode=RES_ADD)
             ln_(tgt, lp + "norm2")
-            msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar)
-            ln_(tgt, lp + "norm1")
+            msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar, norm=lp + "norm1")
             ffn(tgt, T * Q, lp, ar=dar, norm=lp + "norm3")
             if cfg.with_box_refine:
                 bp = f"bbox_embed.{lid}.layers."
@@ -378,9 +389,15 @@ def _swin_backbone(model, frames, ar, sizes):
         for j in range(depth):
             p = f"{b}layers.{i}.blocks.{j}."
             m0 = ar.mark()
-            xn = ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=A(ntok, C))
+            xn = A(ntok, C)
             qkv = A(ntok, 3 * C)
-            gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
+            pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
+            if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
+                ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
+                           ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
+            else:
+                ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
+                gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
             if cfg.video:
                 att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
                                         W, C, nH, j % 2 == 1, out=xn)
@@ -521,10 +538,9 @@ def _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, 
                     sA2=0, sC=hw * D)
             att = A(T * hw, D)
             ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-            gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * hw, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                    ldres=D, res_mode=RES_ADD)
+            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
+                         w[bp + "norm2.bias"])
             ar.release(m1)
-            ln_(tgt, bp + "norm2")
             ffn(tgt, T * hw, bp, norm=bp + "norm3")
         # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
         if y is not None:

@@ -584,3 +584,49 @@ def test_split_fp16_range_guard(ops):
     ops.ffn_fused(x, pk, dev(torch.zeros(C)), Hd, ops.ACT_RELU, out=torch.empty_like(x))
     with pytest.raises(RangeError):
         ops.check_range()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(24100, 256, 256, 1), (4820, 384, 256, 5), (7200, 288, 96, 1), (1000, 576, 192, 2),
+                                         (333, 128, 128, 1), (129, 32, 96, 1)])
+@pytest.mark.parametrize("variant", ["plain", "a2_relu", "res_mul", "gelu_res", "ln_in", "ln_out"])
+def test_rowlin(ops, M, N, K, batch, variant):
+    """Token-stationary linear kernel (tce_rowlin_f32) against torch fp32 of the op sequence it replaces: addend with a
+    shared (stride-0) position map, LayerNorm prologue, activations, residual add / multiply, LayerNorm epilogue,
+    frame-batched launches with per-frame strides, ragged row counts."""
+    if variant == "ln_out" and N != 256:
+        pytest.skip("output LayerNorm is built for N = 256")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(batch, M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.3
+    pos = torch.randn(M, K, generator=g)
+    res = torch.randn(batch, M, N, generator=g)
+    gi, bi = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    go, bo = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    pk = ops.rowlin_pack(dev(w))
+    dx, dres = dev(x), dev(res)
+    out = torch.empty(batch, M, N, device="cuda")
+    kw = dict(bias=dev(b), batch=batch, sX=M * K, sOut=M * N)
+    if variant == "plain":
+        ref = F.linear(x, w, b)
+    elif variant == "a2_relu":
+        kw.update(a2=dev(pos), lda2=K, sA2=0, act=ops.ACT_RELU)
+        ref = F.relu(F.linear(x + pos, w, b))
+    elif variant == "res_mul":
+        kw.update(res=dres, ldres=N, res_mode=ops.RES_MUL, sRes=M * N)
+        ref = F.linear(x, w, b) * res
+    elif variant == "gelu_res":
+        kw.update(act=ops.ACT_GELU, res=dres, ldres=N, res_mode=ops.RES_ADD, sRes=M * N)
+        ref = F.gelu(F.linear(x, w, b)) + res
+    elif variant == "ln_in":
+        kw.update(ln_in=(dev(gi), dev(bi)))
+        ref = F.linear(F.layer_norm(x, (K,), gi, bi, 1e-5), w, b)
+    else:
+        kw.update(res=dres, ldres=N, res_mode=ops.RES_ADD, sRes=M * N, ln_out=(dev(go), dev(bo)))
+        ref = F.layer_norm(F.linear(x, w, b) + res, (N,), go, bo, 1e-5)
+    ops.rowlin(dx, pk, out, M, N, K, K, N, **kw)
+    close(out, ref, 2e-4, 2e-4)
+    if variant == "plain" and batch == 1:   # position map shared by groups of rows inside ONE launch (a2_rows)
+        rows = 97
+        ops.rowlin(dx, pk, out, M, N, K, K, N, bias=dev(b), a2=dev(pos[:rows]), lda2=K, a2_rows=rows)
+        close(out[0], F.linear(x[0] + pos[:rows][torch.arange(M) % rows], w, b), 2e-4, 2e-4)
