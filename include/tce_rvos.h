@@ -126,8 +126,11 @@ int tce_mha_f32(const float* Q, const float* K, const float* V, float* O, int32_
 /* Multi-scale deformable attention forward -- the drop-in for the reference's only native op
  * MultiScaleDeformableAttention_update.ms_deform_attn_forward (models/ops/src/vision.cpp:13-16,
  * ms_deform_attn_cuda.cu:21-102, ms_deform_im2col_cuda.cuh:34-85,320-455):
- *   value [N,S,M,D] (D == 32), spatial_shapes int64 [L,2] (H,W), level_start_index int64 [L] (both DEVICE),
- *   sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]  ->  out [N,Lq,M*D]   (L*P <= 16). */
+ *   value [N,S,M,D], spatial_shapes int64 [L,2] (H,W), level_start_index int64 [L] (both DEVICE),
+ *   sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]  ->  out [N,Lq,M*D].
+ * Any head dim D and any L, P (as the reference kernel, which is templated over channels).  D == 32 runs the
+ * row-gather kernels (one 128-byte value row per corner: 16-byte gathers for L*P <= 16, dword gathers for L*P <= 32);
+ * every other shape runs one thread per output scalar. */
 int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                    const float* sampling_loc, const float* attn_weight, float* out, int32_t N,
                                    int32_t S, int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P,

@@ -12,6 +12,7 @@
 //   each of the four corners is dropped individually when it falls outside the level.
 #include "common.h"
 #include "../../include/tce_rvos.h"
+#include "../../include/tce_rvos_debug.h"
 
 namespace {
 
@@ -41,11 +42,10 @@ __device__ __forceinline__ float bilinear_gather(const float* __restrict__ vbase
   return val;
 }
 
-// FUSED = false: sampling_loc / attn_weight given (the reference op's signature)
-// FUSED = true : raw projection rows (offsets | logits) + reference points
-template <bool FUSED>
-__global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ value, const float* __restrict__ loc_or_proj,
-                                                   const float* __restrict__ aw_or_ref, float* __restrict__ out,
+// Fused form, dword-per-lane (fallback of msda_fused_q4_kernel for operands that are not 16-byte aligned): raw projection
+// rows (offsets | logits) + reference points in, softmax and offset normalisation inside.
+__global__ void __launch_bounds__(256) msda_fused_kernel(const float* __restrict__ value, const float* __restrict__ loc_or_proj,
+                                                         const float* __restrict__ aw_or_ref, float* __restrict__ out,
                                                    LevelInfo lv, int N, int S, int M, int Lq, int L, int P,
                                                    int ref_dim, int ref_per_frame, long long total) {
   const int lane = threadIdx.x & 63;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ val
   float px = 0.f, py = 0.f, pw = 0.f;
   if (active && pj < LP) {
     const int l = pj / P;
-    if (FUSED) {
+    {
       const int ncol = M * LP * 3;
       const float* row = loc_or_proj + ((long long)n * Lq + q) * ncol;
       const float ox = row[(m * LP + pj) * 2 + 0];
@@ -90,14 +90,9 @@ __global__ void __launch_bounds__(256) msda_kernel(const float* __restrict__ val
         px = rp[0] + ox / (float)P * rp[2] * 0.5f;
         py = rp[1] + oy / (float)P * rp[3] * 0.5f;
       }
-    } else {
-      const long long base = (((long long)n * Lq + q) * M + m) * LP + pj;
-      px = loc_or_proj[base * 2 + 0];
-      py = loc_or_proj[base * 2 + 1];
-      pw = aw_or_ref[base];
     }
   }
-  if (FUSED) {
+  {
     // softmax over the LP logits held by lanes 0..LP-1 of each half-wave (xor-shuffles stay inside 16 lanes)
     float v = (active && pj < LP) ? pw : -3.0e38f;
     float mx = v;
@@ -216,6 +211,119 @@ __global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restr
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
 }
 
+// LDS-staged form of the fused kernel for the encoder's self-attention (thousands of queries per frame): a workgroup owns
+// one (frame, head) and a chunk of its queries, and first copies the COARSE levels of that (frame, head) value slice into
+// LDS -- at config 2 levels 1..3 are 1220 rows x 128 B = 152.5 KiB of the 160 KiB -- so that three quarters of the
+// 3.08 M x 4 corner reads of a call are LDS reads; level 0 (3600 rows, 450 KiB per slice) is gathered from the XCD's
+// L2 as before (workgroup b serves head b % 8, so an L2 holds one head).  The staged slice is reused by every query of
+// the chunk (~16x).  Arithmetic and summation order are those of msda_fused_q4_kernel: results are bit-identical.
+constexpr int MSDA_LDS_BYTES = 160 * 1024;
+__global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __restrict__ value, const float* __restrict__ proj,
+                                                              const float* __restrict__ ref, float* __restrict__ out,
+                                                              LevelInfo lv, int N, int S, int Lq, int L, int P, int ref_dim,
+                                                              int ref_per_frame, int first_staged, int staged_rows,
+                                                              int chunks, int qpc_arg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MSDA_LDS_BYTES];
+  constexpr int M = 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sub = lane & 7, gbase = lane & ~7;
+  const int m = blockIdx.x & 7;
+  const int rest = blockIdx.x >> 3;
+  const int n = rest / chunks, c = rest - n * chunks;
+  const long long row_stride = (long long)M * D;
+  const float* vn = value + ((long long)n * S) * row_stride + m * D + sub * 4;
+  const int staged_row0 = lv.start[first_staged];
+  // stage rows [staged_row0, staged_row0 + staged_rows): 8 threads per 128-byte row; every load of a thread is issued
+  // before the first LDS store (a load -> store loop would pay one memory round trip per 16 KiB)
+  {
+    constexpr int NST = MSDA_LDS_BYTES / 16 / 1024;  // 10 pieces of 16 bytes per thread at most
+    f32x4 st[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = min(tid + 1024 * k, staged_rows * 8 - 1);
+      st[k] = *reinterpret_cast<const f32x4*>(value + (((long long)n * S + staged_row0 + (i >> 3)) * M + m) * D + (i & 7) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k)
+      if (tid + 1024 * k < staged_rows * 8) reinterpret_cast<f32x4*>(smem)[tid + 1024 * k] = st[k];
+  }
+  __syncthreads();
+  const int qpc = qpc_arg;
+  const int q0 = c * qpc, q1 = min(Lq, q0 + qpc);
+  const int LP = L * P;
+  const int ncol = M * LP * 3;
+  for (int qb = q0; qb < q1; qb += 128) {
+    const int q = qb + (tid >> 3);
+    const bool active = q < q1;
+    float px[2] = {0.f, 0.f}, py[2] = {0.f, 0.f}, pw[2] = {-3.0e38f, -3.0e38f};
+    bool have[2] = {false, false};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pj = sub + 8 * e;
+      if (active && pj < LP) {
+        have[e] = true;
+        const int l = pj / P;
+        const float* row = proj + ((long long)n * Lq + q) * ncol;
+        const float ox = row[(m * LP + pj) * 2 + 0];
+        const float oy = row[(m * LP + pj) * 2 + 1];
+        pw[e] = row[M * LP * 2 + m * LP + pj];  // logit
+        const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+        if (ref_dim == 2) {
+          px[e] = rp[0] + ox / (float)lv.W[l];
+          py[e] = rp[1] + oy / (float)lv.H[l];
+        } else {
+          px[e] = rp[0] + ox / (float)P * rp[2] * 0.5f;
+          py[e] = rp[1] + oy / (float)P * rp[3] * 0.5f;
+        }
+      }
+    }
+    float mx = fmaxf(pw[0], pw[1]);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e0 = have[0] ? __expf(pw[0] - mx) : 0.f, e1 = have[1] ? __expf(pw[1] - mx) : 0.f;
+    float sum = e0 + e1;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float w0 = e0 / sum, w1 = e1 / sum;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < LP; ++j) {
+      const int src = gbase + (j & 7);
+      const bool hi = j >= 8;  // loop-uniform
+      const float x = __shfl(hi ? px[1] : px[0], src, 64), y = __shfl(hi ? py[1] : py[0], src, 64);
+      const float w = __shfl(hi ? w1 : w0, src, 64);
+      const int l = j / P;
+      const int Hl = lv.H[l], Wl = lv.W[l];
+      const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+      if (active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
+        if (l >= first_staged) {  // loop-uniform: this level lives in LDS
+          const float* lbase = reinterpret_cast<const float*>(smem) + (lv.start[l] - staged_row0) * D + sub * 4;
+          if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_low) * D);
+          if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_high) * D);
+          if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_low) * D);
+          if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_high) * D);
+        } else {
+          const float* vbase = vn + (long long)lv.start[l] * row_stride;
+          if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
+          if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
+          if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
+          if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+        }
+        const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[cc] += w * (c1 * v1[cc] + c2 * v2[cc] + c3 * v3[cc] + c4 * v4[cc]);
+      }
+    }
+    if (active) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q) * M + m) * D + sub * 4) = acc;
+  }
+}
+
 // variant of the plain kernel that reads level geometry from device memory (the reference op passes
 // spatial_shapes / level_start_index as device int64 tensors)
 __global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __restrict__ value,
@@ -320,6 +428,38 @@ __global__ void __launch_bounds__(256) msda_plain_q4_dev_kernel(const float* __r
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
 }
 
+// Generic form of the reference op: any head dim D, any L*P.  One thread per (item, channel); the L*P sampling points
+// are walked in order with the sampling locations read straight from memory (the reference kernel is templated over
+// channels the same way: one thread per output scalar, ms_deform_im2col_cuda.cuh:320-455).  Used for head dims other
+// than 32 (the reference's own self-test runs D = 2 and 30/64/71/..., models/ops/test.py:21-26,85-86) and L*P > 32.
+__global__ void __launch_bounds__(256) msda_generic_dev_kernel(const float* __restrict__ value,
+                                                               const int64_t* __restrict__ shapes,
+                                                               const int64_t* __restrict__ starts,
+                                                               const float* __restrict__ loc,
+                                                               const float* __restrict__ aw, float* __restrict__ out,
+                                                               int S, int M, int Dh, int Lq, int L, int P,
+                                                               long long total_scalars) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_scalars) return;
+  const int d = (int)(idx % Dh);
+  const long long item = idx / Dh;  // (n*Lq + q)*M + m
+  const int m = (int)(item % M);
+  const int n = (int)(item / M / Lq);
+  const long long row_stride = (long long)M * Dh;
+  const float* vn = value + ((long long)n * S) * row_stride + (long long)m * Dh + d;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const float* vl = vn + starts[l] * row_stride;
+    for (int pt = 0; pt < P; ++pt) {
+      const long long base = item * (L * P) + l * P + pt;
+      const float x = loc[base * 2 + 0], y = loc[base * 2 + 1], w = aw[base];
+      acc += w * bilinear_gather(vl, Hl, Wl, row_stride, y * (float)Hl - 0.5f, x * (float)Wl - 0.5f);
+    }
+  }
+  out[idx] = acc;
+}
+
 }  // namespace
 
 extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -328,10 +468,15 @@ extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t*
                                               int32_t Dh, int32_t Lq, int32_t L, int32_t P, tceStream stream) {
   TCE_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
                 "tce_ms_deform_attn_forward_f32: null pointer");
-  TCE_CHECK_ARG(Dh == D, "tce_ms_deform_attn_forward_f32: head dim must be 32 (got %d)", Dh);
-  TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 32,
-                "tce_ms_deform_attn_forward_f32: bad sizes (L*P must be <= 32)");
+  TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Dh > 0 && Lq > 0 && L > 0 && P > 0, "tce_ms_deform_attn_forward_f32: bad sizes");
   const long long total = (long long)N * Lq * M;
+  if (Dh != D || L * P > 32) {  // generic head dim / point count: one thread per output scalar
+    const long long scalars = total * Dh;
+    hipLaunchKernelGGL(msda_generic_dev_kernel, dim3(tce_cdiv(scalars, 256)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, Dh, Lq, L, P, scalars);
+    TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
+    return TCE_OK;
+  }
   if (L * P <= 16 && tce_aligned16(value) && tce_aligned16(out)) {
     hipLaunchKernelGGL(msda_plain_q4_dev_kernel, dim3(tce_cdiv(total, 32)), dim3(256), 0, (hipStream_t)stream, value,
                        spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
@@ -341,6 +486,16 @@ extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t*
   hipLaunchKernelGGL(msda_plain_dev_kernel, dim3(tce_cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
   TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
+  return TCE_OK;
+}
+
+// Measured (tools/msda_bench.py, profiles/r02_msda_lds.txt): the LDS-staged form is bit-identical and NOT faster than the
+// L2-gather form (102 vs 98 us at config 2, 150 vs 151 at config 3, 396 vs 325 at config 5): the gather is bound by
+// the number of wave-instructions per sample (shuffles, address arithmetic, 4 x 16-byte loads, 16 FMAs), not by where
+// the rows come from.  It stays in the library, off by default (tce_debug_msda_set_lds(1) selects it).
+static int g_msda_lds = 0;
+extern "C" int tce_debug_msda_set_lds(int32_t on) {
+  g_msda_lds = on;
   return TCE_OK;
 }
 
@@ -366,6 +521,23 @@ extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const f
   }
   TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
   const long long total = (long long)N * Lq * M;
+  if (M == 8 && Lq >= 2048 && g_msda_lds && tce_aligned16(value) && tce_aligned16(out)) {
+    // LDS-staged form: the largest suffix of levels whose (frame, head) slice fits the LDS
+    int first = L;
+    while (first > 1 && (long long)(start - lv.start[first - 1]) * D * 4 <= MSDA_LDS_BYTES) --first;
+    if (first < L) {
+      const int staged_rows = start - lv.start[first];
+      // queries per workgroup: a multiple of the 128 queries one pass covers, ~2 workgroups per CU over the launch
+      int want = tce_cdiv(512, N * 8);
+      if (want < 1) want = 1;
+      const int qpc = tce_cdiv(tce_cdiv(Lq, want), 128) * 128;
+      const int chunks = tce_cdiv(Lq, qpc);
+      hipLaunchKernelGGL(msda_fused_lds_kernel, dim3(N * chunks * 8), dim3(1024), 0, (hipStream_t)stream, value, proj, ref,
+                         out, lv, N, S, Lq, L, P, ref_dim, ref_per_frame, first, staged_rows, chunks, qpc);
+      TCE_CHECK_LAUNCH("tce_msda_fused_f32(lds)");
+      return TCE_OK;
+    }
+  }
   if (tce_aligned16(value) && tce_aligned16(out)) {  // 16-byte form: 32 items per workgroup
     const int nb = (M == 8) ? tce_cdiv((long long)N * Lq, 32) * 8 : tce_cdiv(total, 32);
     hipLaunchKernelGGL(msda_fused_q4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out, lv, N, S, M,
@@ -375,7 +547,7 @@ extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const f
   }
   // M == 8: 8 workgroups (one per head / XCD) per group of 8 (frame, query) pairs
   const int nblocks = (M == 8) ? tce_cdiv((long long)N * Lq, 8) * 8 : tce_cdiv(total, 8);
-  hipLaunchKernelGGL((msda_kernel<true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, proj, ref,
+  hipLaunchKernelGGL(msda_fused_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, proj, ref,
                      out, lv, N, S, M, Lq, L, P, ref_dim, ref_per_frame, total);
   TCE_CHECK_LAUNCH("tce_msda_fused_f32");
   return TCE_OK;

@@ -224,28 +224,39 @@ def test_mha_core(ops, batch, nh, Lq, Lk, masked):
 
 
 def test_msda_reference_op_matches_reference_fixture(ops):
-    """The drop-in for ms_deform_attn_forward against outputs of the reference's own core (golden fixture);
-    tolerance is the reference's own float check (models/ops/test.py:56: rtol 1e-2, atol 1e-3) -- we ask for 1e-4."""
+    """The drop-in for ms_deform_attn_forward against outputs of the reference's own core (golden fixture), INCLUDING the
+    reference's own known-answer case (models/ops/test.py:21-26: D = 2); tolerance is the reference's own float check
+    (models/ops/test.py:56: rtol 1e-2, atol 1e-3) -- we ask for 1e-4."""
     fx = load_npz("msda_cases.npz")
+    dims = set()
     for i in range(int(fx["n_cases"])):
         shapes = torch.from_numpy(fx[f"c{i}_shapes"])
         value = torch.from_numpy(fx[f"c{i}_value"])
-        if value.shape[-1] != 32:
-            continue  # D=2 case of the reference test: outside the kernel's contract (checked below to be rejected)
+        dims.add(value.shape[-1])
         lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
         out = ops.ms_deform_attn_forward(dev(value), shapes.cuda(), lsi.cuda(), dev(torch.from_numpy(fx[f"c{i}_loc"])),
                                          dev(torch.from_numpy(fx[f"c{i}_w"])))
         close(out, torch.from_numpy(fx[f"c{i}_out"]), 1e-4, 1e-5)
+    assert 2 in dims and 32 in dims
 
 
-def test_msda_rejects_unsupported_head_dim(ops):
-    from tce_rvos_amd._lib import TceError
-    fx = load_npz("msda_cases.npz")
-    shapes = torch.from_numpy(fx["c0_shapes"])
+@pytest.mark.parametrize("N,Lq,M,Dh,L,P", [(2, 50, 8, 32, 4, 8),     # L*P = 32: dword row-gather kernel
+                                           (1, 33, 4, 32, 8, 8),     # L*P = 64: generic kernel
+                                           (2, 17, 3, 30, 2, 3), (1, 9, 2, 71, 3, 2), (2, 5, 8, 64, 4, 4),  # test.py:85-86 dims
+                                           (1, 40, 8, 32, 4, 4)])    # the 16-byte gather kernel
+def test_msda_reference_op_generic_shapes(ops, N, Lq, M, Dh, L, P):
+    """Head dims and point counts beyond the model's (8 x 32, 4 x 4) against the oracle's restatement of the reference
+    core (itself pinned to the reference by the fixture test above); locations include out-of-range samples."""
+    g = torch.Generator().manual_seed(N * 1000 + Dh + L * P)
+    shapes = torch.tensor([(6 + 2 * l, 5 + 3 * l) for l in range(L)][::-1], dtype=torch.int64)
+    S = int(shapes.prod(1).sum())
     lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
-    with pytest.raises(TceError):
-        ops.ms_deform_attn_forward(dev(torch.from_numpy(fx["c0_value"])), shapes.cuda(), lsi.cuda(),
-                                   dev(torch.from_numpy(fx["c0_loc"])), dev(torch.from_numpy(fx["c0_w"])))
+    value = torch.randn(N, S, M, Dh, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.6 - 0.3
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    out = ops.ms_deform_attn_forward(dev(value), shapes.cuda(), lsi.cuda(), dev(loc), dev(aw))
+    ref = O.msda_core(value, [(int(h), int(w)) for h, w in shapes], loc, aw)
+    close(out, ref, 1e-4, 1e-5)
 
 
 @pytest.mark.parametrize("N,Lq,ref_dim", [(2, 300, 2), (3, 5, 4), (1, 8, 2)])
@@ -630,3 +641,32 @@ def test_rowlin(ops, M, N, K, batch, variant):
         rows = 97
         ops.rowlin(dx, pk, out, M, N, K, K, N, bias=dev(b), a2=dev(pos[:rows]), lda2=K, a2_rows=rows)
         close(out[0], F.linear(x[0] + pos[:rows][torch.arange(M) % rows], w, b), 2e-4, 2e-4)
+
+
+def test_msda_fused_lds_staged_is_bit_identical(ops):
+    """Encoder-sized call (thousands of queries per frame): the LDS-staged kernel (coarse levels of a (frame, head) slice
+    in LDS) against the L2-gather kernel it replaces -- same arithmetic, same order: bit-identical -- and against the
+    oracle's restatement of the reference core."""
+    from tce_rvos_amd._lib import lib
+    g = torch.Generator().manual_seed(77)
+    N, M, L, P = 2, 8, 4, 4
+    shapes = [(45, 80), (23, 40), (12, 20), (6, 10)]   # config 2's levels
+    S = sum(h * w for h, w in shapes)
+    Lq = S
+    value = torch.randn(N, S, M, 32, generator=g)
+    proj = torch.randn(N, Lq, M * L * P * 3, generator=g)
+    proj[..., :M * L * P * 2] *= 3.0
+    ref = torch.rand(Lq, 2, generator=g) * 1.1 - 0.05
+    dv, dp, dr = dev(value), dev(proj), dev(ref)
+    b = ops.msda_fused(dv, dp, dr, shapes, N, S, M, Lq, L, P, 2, False)
+    lib().tce_debug_msda_set_lds(1)
+    try:
+        a = ops.msda_fused(dv, dp, dr, shapes, N, S, M, Lq, L, P, 2, False)
+    finally:
+        lib().tce_debug_msda_set_lds(0)
+    assert torch.equal(a, b)
+    off = proj[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+    aw = torch.softmax(proj[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32)
+    loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    close(a.view(N, Lq, M * 32), O.msda_core(value, shapes, loc, aw), 1e-4, 1e-4)
