@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the value_f32_exact / value_text_cached passes")
-    ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3", "f16"],
+                    help="f16x3 (default): fp32-accurate 3 x fp16 split; f32: exact fp32 MFMA; f16: one fp16 MFMA per product (config 5)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (+ TCE_BENCH_ONE_DEVICE=1: every rank on cuda:0) rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--clips-in-flight", type=int, default=1,
@@ -112,8 +113,8 @@ def main():
     margs = argparse.Namespace(backbone=args.backbone, with_box_refine=True, binary=True, freeze_text_encoder=True,
                                f_token=8, qtrans=True, num_feature_levels=4)
     model, _, _ = build_model(margs)
+    ops.set_gemm_mode(args.gemm_mode)  # before the weights are packed: packed streams carry the mode's rounding
     model = model.to(dev).eval()
-    ops.set_gemm_mode(args.gemm_mode)
     C = max(1, args.clips_in_flight)
     if C > 1 and not model.use_graph:
         raise SystemExit("--clips-in-flight > 1 needs graph replay (TCE_GRAPH=1): eager launches share one stream per slot")
@@ -208,6 +209,7 @@ def main():
         # f32: v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s).  f16x3: three v_mfma_f32_32x32x16_f16 per algorithmic product
         # (dense fp16 peak 2500 TFLOP/s): `achieved` stays ALGORITHMIC 2*M*N*K, the MFMA pipe issues 3x that.
         peak = 157.3 if mode == "f32" else 2500.0
+        passes = {"f32": 1, "f16x3": 3, "f16": 1}[mode]
         ach = fl / sec / 1e12
         if isinstance(key[0], str):
             kname = key[0]
@@ -216,7 +218,7 @@ def main():
             kname = ("gemm_f32_kernel" if mode == "f32" else "gemm_f16x3_kernel") + f"<{tname}" + (" conv>" if key[1] else ">")
         traffic, tsrc = _pmc_traffic(kname.split(" conv")[0].rstrip(">"))
         roofline = {"bound": "mfma", "kernel": kname, "gemm_mode": mode,
-                    "mfma_issued_tflops": round(ach * (1 if mode == "f32" else 3), 2),
+                    "mfma_issued_tflops": round(ach * passes, 2),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     # what a bare loop of this MFMA + an LDS fragment feed sustains with all 256 CUs issuing: the chip
                     # lowers its clock under matrix load; informative, `peak` stays the guide's
@@ -233,11 +235,11 @@ def main():
         model.text_cache_size, use_host_ids = 8, True
         variants["value_text_cached"] = round(n_var / timed(n_var, 6, gather=False), 3)
         model.text_cache_size, use_host_ids = 0, False
-        if args.gemm_mode == "f16x3":
+        if args.gemm_mode != "f32":
             ops.set_gemm_mode("f32")
             model.repack()  # captured graphs hold the split-mode kernels
             variants["value_f32_exact"] = round(n_var / timed(n_var, 6, gather=False), 3)
-            ops.set_gemm_mode("f16x3")
+            ops.set_gemm_mode(args.gemm_mode)
             model.repack()
 
     cpu_baseline, parity = None, None
@@ -250,7 +252,9 @@ def main():
         with torch.no_grad():
             hid, pooled = model.forward_text_encoder(ids[0], dev)
             hid, pooled = hid.cpu(), pooled.cpu()
-            cfg = O.OracleConfig(backbone=args.backbone)
+            from tce_rvos_amd.config import BACKBONES
+            bb = BACKBONES[args.backbone]
+            cfg = O.OracleConfig(backbone=args.backbone, **{k: bb[k] for k in ("embed_dim", "depths", "num_heads") if k in bb})
             times = []
             for _ in range(2):
                 t1 = time.perf_counter()
@@ -280,7 +284,9 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "timed_region_s": round(elapsed, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.gemm_mode == "f32" else "f32 (3xf16-split MFMA, f32 accumulate)", "data": "synthetic",
+                "dtype": {"f32": "f32", "f16x3": "f32 (3xf16-split MFMA, f32 accumulate)",
+                          "f16": "f16 (operands rounded to fp16, one MFMA per product, f32 accumulate)"}[args.gemm_mode],
+                "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
                            "clips_per_step": world * C, "clips_in_flight_per_gpu": C,

@@ -58,8 +58,11 @@ int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspac
 /* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
 int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t conv);
-/* arithmetic used by tce_gemm_f32: 0 = exact fp32 MFMA; 1 (default) = fp32 operands split on the fly into two fp16
- * halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to ~3e-7 per product, 5x the MFMA rate). */
+/* arithmetic used by tce_gemm_f32 and the fused kernels: 0 = exact fp32 MFMA (fused kernels off); 1 (default) = fp32
+ * operands split on the fly into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation (fp32-accurate to
+ * ~3e-7 per product); 2 = ONE fp16 MFMA per product on operands rounded to nearest fp16, fp32 accumulation (BASELINE
+ * config 5's "fp16 MFMA"; relative error ~5e-4 per product).  Weight streams packed by tce_ffn_pack_f32 /
+ * tce_rowlin_pack_f32 carry the rounding of the mode they were packed in: re-pack after switching. */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
 

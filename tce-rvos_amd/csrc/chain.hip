@@ -64,9 +64,21 @@ struct HL {
   h16x8 hi, lo;
 };
 
-// 8 fp32 -> fp16 hi (truncated) + fp16 lo (truncated exact remainder); element j of the fragment = v[j]
-__device__ __forceinline__ HL split8(const float* v) {
+// 8 fp32 -> fp16 hi (truncated) + fp16 lo (truncated exact remainder); element j of the fragment = v[j].
+// single (tce_set_gemm_mode(2)): hi = the value rounded to NEAREST fp16, lo unused (zero)
+__device__ __forceinline__ HL split8(const float* v, const int single = 0) {
   u32x4 h, l;
+  if (single) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h[q] = __builtin_bit_cast(unsigned, fp16x2_t{(__fp16)v[2 * q], (__fp16)v[2 * q + 1]});
+      l[q] = 0u;
+    }
+    HL r;
+    r.hi = __builtin_bit_cast(h16x8, h);
+    r.lo = __builtin_bit_cast(h16x8, l);
+    return r;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]);
@@ -98,7 +110,8 @@ __device__ __forceinline__ void load_x_frags(const float* __restrict__ x, const 
                                              const float* __restrict__ a2, const long long lda2, const int a2_rows,
                                              const int m0, const int M, float* __restrict__ wt, const int lane,
                                              const float* __restrict__ g_in, const float* __restrict__ be_in,
-                                             const float eps, h16x8 (&xh)[K / 16], h16x8 (&xl)[K / 16]) {
+                                             const float eps, h16x8 (&xh)[K / 16], h16x8 (&xl)[K / 16],
+                                             const int single = 0) {
   constexpr int NP = K / 32;
   const int cr = lane >> 3, cp = (lane & 7) * 4;
   const int r = lane & 31, hf = lane >> 5;
@@ -160,7 +173,7 @@ __device__ __forceinline__ void load_x_frags(const float* __restrict__ x, const 
       const f32x4 a = *reinterpret_cast<const f32x4*>(pr);
       const f32x4 b = *reinterpret_cast<const f32x4*>(pr + 4);
       const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      const HL sp = split8(f);
+      const HL sp = split8(f, single);
       xh[2 * q + h] = sp.hi;
       xl[2 * q + h] = sp.lo;
     }
@@ -293,6 +306,7 @@ struct FfnArgs {
   int M, NI;  // NI = hidden/32 + 1 iterations
   float eps_in, eps_out;
   int* range_flag;  // tce_set_range_flag: set when a hidden or an output value leaves the fp16 range of the split
+  int single;       // tce_set_gemm_mode(2): one MFMA per product on nearest-rounded fp16 operands
 };
 
 template <int C, int WAVES, int ACT>
@@ -337,7 +351,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
   float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<C>(p.x, p.ldx, nullptr, 0, 0, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl);
+  load_x_frags<C>(p.x, p.ldx, nullptr, 0, 0, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
 
   f32x16 oacc[NT];
 #pragma unroll
@@ -345,6 +359,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
   tce_amax_t amax = 0;
+  const int single = p.single;
   h16x8 hh0, hl0, hh1, hl1;  // H^T of the previous chunk as B fragments (k-steps 0 and 1)
 #pragma unroll
   for (int j = 0; j < 8; ++j) hh0[j] = hl0[j] = hh1[j] = hl1[j] = (_Float16)0.f;
@@ -381,18 +396,24 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
       if (FFN_ABL & 4) {
         asm volatile("" ::"v"(ah), "v"(al));
       } else if (s < KS) {
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], hacc, 0, 0, 0);
+        if (!single) {
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], hacc, 0, 0, 0);
+        }
         hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[s], hacc, 0, 0, 0);
       } else {
         const int j = s - KS, t = j >> 1;
         if (j & 1) {
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hl1, oacc[t], 0, 0, 0);
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, hh1, oacc[t], 0, 0, 0);
+          if (!single) {
+            oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hl1, oacc[t], 0, 0, 0);
+            oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, hh1, oacc[t], 0, 0, 0);
+          }
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hh1, oacc[t], 0, 0, 0);
         } else {
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hl0, oacc[t], 0, 0, 0);
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, hh0, oacc[t], 0, 0, 0);
+          if (!single) {
+            oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hl0, oacc[t], 0, 0, 0);
+            oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, hh0, oacc[t], 0, 0, 0);
+          }
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hh0, oacc[t], 0, 0, 0);
         }
         // activation + hi/lo split of value pairs [8j/(2NT), 8(j+1)/(2NT)) of this chunk, spread over the 2NT steps
@@ -408,7 +429,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
             v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
           }
           amax = max(amax, max(tce_absbits(v0), tce_absbits(v1)));
-          const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+          const fp16x2_t a = single ? fp16x2_t{(__fp16)v0, (__fp16)v1} : __builtin_amdgcn_cvt_pkrtz(v0, v1);
           const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz(v0 - (float)a[0], v1 - (float)a[1]);
           unsigned wa = __builtin_bit_cast(unsigned, a), wb = __builtin_bit_cast(unsigned, b);
           asm volatile("" : "+v"(wa), "+v"(wb));  // anchors the computation in this step (the optimiser would sink it)
@@ -468,7 +489,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, unsigned char* __restrict__ out,
                                                        const int C, const int Hd, const int P,
-                                                       const long long units) {
+                                                       const long long units, const int single) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= units) return;
   const int KS = C / 16, NT = C / 32, NC = Hd / 32;
@@ -534,6 +555,7 @@ struct LinArgs {
   int M, N, a2_rows, act, res_mode;
   float eps_in, eps_out;
   int* range_flag;
+  int single;
 };
 
 template <int K, bool ROW>
@@ -590,7 +612,8 @@ __global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs 
 
   float* const wt = reinterpret_cast<float*>(smem + 3 * HSTAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<K>(x, p.ldx, a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl);
+  load_x_frags<K>(x, p.ldx, a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
+  const int single = p.single;
   tce_amax_t amax = 0;
   if (stamps) stamps[6] = (long long)__builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -619,8 +642,10 @@ __global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs 
       }
       if (s < SLOTS) dma_half(s);
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s % 3], xl[S0 + s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s % 3], xh[S0 + s], acc, 0, 0, 0);
+      if (!single) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s % 3], xl[S0 + s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s % 3], xh[S0 + s], acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s % 3], xh[S0 + s], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -712,7 +737,7 @@ __global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs 
 // halves ahead).
 __global__ void __launch_bounds__(256) rowlin_pack_kernel(const float* __restrict__ W, unsigned char* __restrict__ out,
                                                           const int N, const int K, const long long ldw,
-                                                          const long long units) {
+                                                          const long long units, const int single) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= units) return;
   const int KH = K / 32, HP = (2 * KH + 3) / 4 * 4;
@@ -728,7 +753,7 @@ __global__ void __launch_bounds__(256) rowlin_pack_kernel(const float* __restric
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = W[(long long)n * ldw + 16 * s + 8 * hf + j];
-    const HL f = split8(v);
+    const HL f = split8(v, single);
     o = __builtin_bit_cast(u32x4, (piece & 1) ? f.lo : f.hi);
   }
   reinterpret_cast<u32x4*>(out)[u] = o;
@@ -783,7 +808,7 @@ extern "C" int tce_ffn_pack_f32(const float* W1, const float* b1, const float* W
   TCE_CHECK_ARG(W1 && W2 && packed && tce_aligned16(packed), "tce_ffn_pack_f32: null / misaligned pointer");
   const long long units = ffn_units(C, Hd);
   hipLaunchKernelGGL(ffn_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W1, b1, W2,
-                     (unsigned char*)packed, C, Hd, ffn_pieces(C), units);
+                     (unsigned char*)packed, C, Hd, ffn_pieces(C), units, tce_gemm_single_pass());
   TCE_CHECK_LAUNCH("tce_ffn_pack_f32");
   return TCE_OK;
 }
@@ -804,7 +829,7 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   FfnArgs a;
   a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2;
   a.g_in = g_in; a.be_in = be_in; a.g_out = g_out; a.be_out = be_out;
-  a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag();
+  a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
   hipStream_t s = (hipStream_t)stream;
   if (C == 256) ffn_launch<256, 4>(a, act, s);
   else if (C == 192) ffn_launch<192, 4>(a, act, s);
@@ -821,7 +846,7 @@ extern "C" int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, in
   TCE_CHECK_ARG(W && packed && tce_aligned16(packed) && ldw >= K, "tce_rowlin_pack_f32: null / misaligned pointer or ldw < K");
   const long long units = rowlin_units(N, K);
   hipLaunchKernelGGL(rowlin_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W,
-                     (unsigned char*)packed, N, K, (long long)ldw, units);
+                     (unsigned char*)packed, N, K, (long long)ldw, units, tce_gemm_single_pass());
   TCE_CHECK_LAUNCH("tce_rowlin_pack_f32");
   return TCE_OK;
 }
@@ -850,7 +875,7 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   a.ldx = q.ldx; a.lda2 = q.lda2; a.ldres = q.ldres; a.ldo = q.ldo;
   a.sX = q.sX; a.sA2 = q.sA2; a.sRes = q.sRes; a.sOut = q.sOut;
   a.M = q.M; a.N = q.N; a.a2_rows = q.a2_rows; a.act = q.act; a.res_mode = q.res_mode;
-  a.eps_in = q.eps_in; a.eps_out = q.eps_out; a.range_flag = tce_range_flag();
+  a.eps_in = q.eps_in; a.eps_out = q.eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
   const int batch = q.batch > 0 ? q.batch : 1;
   const bool row = q.g_out != nullptr;
   hipStream_t s = (hipStream_t)stream;

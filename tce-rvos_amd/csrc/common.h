@@ -13,6 +13,9 @@ void tce_set_error(const char* fmt, ...);
 // device int32 registered with tce_set_range_flag (NULL = check disabled); see include/tce_rvos.h
 int* tce_range_flag();
 #define TCE_RANGE_LIMIT 60000.f
+// 1 when tce_set_gemm_mode(2) is active: the fp16 kernels issue ONE MFMA per product on operands rounded to nearest
+// fp16 (fp32 accumulate) instead of the three of the hi/lo split (defined in gemm.hip)
+int tce_gemm_single_pass();
 
 #define TCE_CHECK_ARG(cond, ...)            \
   do {                                      \

@@ -195,10 +195,13 @@ int launch(const tceGemmArgs& a, hipStream_t s) {
 int tce_gemm_f16x3_launch_big(const tceGemmArgs& a, int tile, hipStream_t s);    // gemm_f16x3_big.hip
 int tce_gemm_f16x3_launch_small(const tceGemmArgs& a, int tile, hipStream_t s);  // gemm_f16x3_small.hip
 
-static int g_gemm_mode = 1;  // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate)
+// 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate);
+// 2: single fp16 MFMA per product, operands rounded to nearest fp16, fp32 accumulate (BASELINE config 5's arithmetic)
+static int g_gemm_mode = 1;
+int tce_gemm_single_pass() { return g_gemm_mode == 2; }
 
 extern "C" int tce_set_gemm_mode(int32_t mode) {
-  TCE_CHECK_ARG(mode == 0 || mode == 1, "tce_set_gemm_mode: mode must be 0 (f32) or 1 (3xf16 split)");
+  TCE_CHECK_ARG(mode >= 0 && mode <= 2, "tce_set_gemm_mode: mode must be 0 (f32), 1 (3xf16 split) or 2 (single f16)");
   g_gemm_mode = mode;
   return TCE_OK;
 }
@@ -220,7 +223,7 @@ static int select_tile_ex(int M, int N, int K, int batch, int conv) {
   const long long n256 = (long long)tce_cdiv(M, 256) * tce_cdiv(N, 128) * b;
   const long long n128 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 128) * b;
   const long long n12864 = (long long)tce_cdiv(M, 128) * tce_cdiv(N, 64) * b;
-  if (g_gemm_mode == 1) {
+  if (g_gemm_mode >= 1) {
     // measured on MI355X (tools/gemm_bench.py): the 8-wave 256x128 tile wins once it fills the chip 1.5x and the
     // problem is wide or deep; 128x128 for the big implicit-GEMM convolutions; the small tiles elsewhere
     // (tools/gemm_shape_sweep.py over every launch of a config-2 clip: deep-K / wide problems already prefer the
@@ -285,7 +288,7 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
     TCE_CHECK_ARG(a.Cin % BK == 0, "tce_gemm_f32: conv Cin=%d must be a multiple of %d", a.Cin, BK);
     // batch > 1 with conv = split-K chunks of one convolution (only issued by tce_gemm_splitk_f32, split-fp16 mode)
     TCE_CHECK_ARG((long long)a.K * a.batch == (long long)a.kh * a.kw * a.Cin, "tce_gemm_f32: conv K=%d x batch != kh*kw*Cin", a.K);
-    TCE_CHECK_ARG(a.batch == 1 || g_gemm_mode == 1, "tce_gemm_f32: split convolutions need the split-fp16 mode");
+    TCE_CHECK_ARG(a.batch == 1 || g_gemm_mode >= 1, "tce_gemm_f32: split convolutions need an fp16-MFMA mode");
     TCE_CHECK_ARG(a.M == a.T * a.Ho * a.Wo, "tce_gemm_f32: conv M=%d != T*Ho*Wo", a.M);
     TCE_CHECK_ARG(a.Ho == (a.H + 2 * a.pad - a.kh) / a.stride + 1 && a.Wo == (a.Wd + 2 * a.pad - a.kw) / a.stride + 1,
                   "tce_gemm_f32: conv output size mismatch");
@@ -309,7 +312,7 @@ extern "C" int tce_gemm_f32(const tceGemmArgs* args, tceStream stream) {
     a.res_mode = 0;
   }
   const int tile = select_tile_ex(a.M, a.N, a.K, a.batch, a.conv);
-  if (g_gemm_mode == 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
+  if (g_gemm_mode >= 1 && a.K % 32 == 0 && (!a.conv || a.Cin % 32 == 0)) {
     if (tile == 256128 || tile == 128128) tce_gemm_f16x3_launch_big(a, tile, s);
     else tce_gemm_f16x3_launch_small(a, tile, s);
     TCE_CHECK_LAUNCH("tce_gemm_f32(f16x3)");
@@ -360,7 +363,7 @@ extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, floa
   tceGemmArgs a = *args;
   TCE_CHECK_ARG(splits >= 1 && splits <= 64, "tce_gemm_splitk_f32: splits=%d out of range", splits);
   TCE_CHECK_ARG(a.batch <= 1, "tce_gemm_splitk_f32: un-batched problems only");
-  if (a.conv && (g_gemm_mode != 1 || a.Cin % 32 != 0)) splits = 1;  // the exact-fp32 kernel has no split convolution
+  if (a.conv && (g_gemm_mode < 1 || a.Cin % 32 != 0)) splits = 1;  // the exact-fp32 kernel has no split convolution
   TCE_CHECK_ARG(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.K > 0 && a.K % (splits * BK) == 0,
                 "tce_gemm_splitk_f32: N=%d must be a multiple of 4 and K=%d a multiple of splits*%d", a.N, a.K, BK);
   TCE_CHECK_ARG(a.C && tce_aligned16(workspace), "tce_gemm_splitk_f32: null C / unaligned workspace");

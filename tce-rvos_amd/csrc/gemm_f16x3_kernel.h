@@ -49,8 +49,15 @@ struct h4pair {
   fp16x2_t a, b;
 };
 
-// hi by truncation (v_cvt_pkrtz_f16_f32), lo = the exact remainder, truncated
-__device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo) {
+// hi by truncation (v_cvt_pkrtz_f16_f32), lo = the exact remainder, truncated.  single (tce_set_gemm_mode(2)): hi is
+// the value rounded to NEAREST fp16 and lo is not used
+__device__ __forceinline__ void split4_rtz(const f32x4 v, h4pair& hi, h4pair& lo, const int single = 0) {
+  if (single) {
+    hi.a = fp16x2_t{(__fp16)v[0], (__fp16)v[1]};
+    hi.b = fp16x2_t{(__fp16)v[2], (__fp16)v[3]};
+    lo.a = lo.b = fp16x2_t{(__fp16)0.f, (__fp16)0.f};
+    return;
+  }
   hi.a = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
   hi.b = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
   const float d0 = v[0] - (float)hi.a[0], d1 = v[1] - (float)hi.a[1];
@@ -71,7 +78,8 @@ static __device__ int g_epi_lds = 1;  // tuning aid: 1 = LDS-staged coalesced ep
 // round trip, which is what bounds the small / short-K problems of this path.
 template <int BM, int BN, int WAVES_M, bool CONV, bool HAS_A2, int DEPTH>
 __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
-    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n, int* const range_flag) {
+    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n, int* const range_flag,
+                      const int single) {
   constexpr int NT = 128 * WAVES_M;                   // threads: WAVES_M x 2 waves
   constexpr int RP = NT / 8;                          // tile rows covered by one loader pass
   constexpr int WM = BM / WAVES_M, WN = BN / 2;
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
       f32x4 av = xa[i];
       if (HAS_A2) av += xa2[i];
       h4pair hi, lo;
-      split4_rtz(((mask >> i) & 1u) ? av : zero, hi, lo);
+      split4_rtz(((mask >> i) & 1u) ? av : zero, hi, lo, single);
       *reinterpret_cast<h4pair*>(st + off) = hi;
       *reinterpret_cast<h4pair*>(st + PLANE_A + off) = lo;
     }
@@ -183,7 +191,7 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
       const int row = lrow + RP * i;
       const int off = swz(row, kq >> 1) + ((kq & 1) << 3);
       h4pair hi, lo;
-      split4_rtz(((mask >> (8 + i)) & 1u) ? xb[i] : zero, hi, lo);
+      split4_rtz(((mask >> (8 + i)) & 1u) ? xb[i] : zero, hi, lo, single);
       *reinterpret_cast<h4pair*>(st + 2 * PLANE_A + off) = hi;
       *reinterpret_cast<h4pair*>(st + 2 * PLANE_A + PLANE_B + off) = lo;
     }
@@ -220,8 +228,10 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           // operands swapped: D[n][m] -- the lane owns an output row (see tce_epi_store_t)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+          if (!single) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         }
     }
@@ -295,11 +305,11 @@ void launch(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1), block(128 * WAVES_M);
   if (a.conv)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
   else if (a.A2)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
   else
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag());
+    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
 }
 
 

@@ -72,12 +72,14 @@ def _gemm_launch(g, splitk=1, ws=None):
 
 
 def set_gemm_mode(mode):
-    """'f32' = exact fp32 MFMA; 'f16x3' (default) = fp32 operands split into two fp16 halves, 3 fp16 MFMAs per product."""
-    check(lib().tce_set_gemm_mode({"f32": 0, "f16x3": 1}[mode]), "tce_set_gemm_mode")
+    """'f32' = exact fp32 MFMA; 'f16x3' (default) = fp32 operands split into two fp16 halves, 3 fp16 MFMAs per product;
+    'f16' = one fp16 MFMA per product on operands rounded to fp16, fp32 accumulate (BASELINE config 5).  Packed weight
+    streams carry the mode's rounding: call model.repack() after switching."""
+    check(lib().tce_set_gemm_mode({"f32": 0, "f16x3": 1, "f16": 2}[mode]), "tce_set_gemm_mode")
 
 
 def get_gemm_mode():
-    return {0: "f32", 1: "f16x3"}[lib().tce_get_gemm_mode()]
+    return {0: "f32", 1: "f16x3", 2: "f16"}[lib().tce_get_gemm_mode()]
 
 
 def _stream():
@@ -149,7 +151,7 @@ def check_weight_range(named_tensors):
     for name, t in named_tensors:
         if t.is_floating_point() and t.numel() and not bool(t.abs().max() < FP16_RANGE_LIMIT):
             bad.append(name)
-    if bad and get_gemm_mode() == "f16x3":
+    if bad and get_gemm_mode() != "f32":
         raise RangeError(f"parameters outside the fp16 range of the split-fp16 GEMM arithmetic (|w| >= {FP16_RANGE_LIMIT:g} or "
                          f"non-finite): {bad[:5]}{'...' if len(bad) > 5 else ''}.  Select the exact fp32 kernels with "
                          f"ops.set_gemm_mode('f32') before loading these weights.")
@@ -482,7 +484,7 @@ def _rowlin_route(w, M, N, K, ldw, batch):
     """Packed copy of a registered weight when the token-stationary kernel measured faster than the tiled GEMM for this
     shape (tools/rowlin_bench.py): K = 96 / 128 with many rows (Swin stage 1, the stride-4 adapter), and K = 192 / 256
     with N >= 384 (the 384-wide offset/weight projection, the 512-wide q|k projection)."""
-    if K not in ROWLIN_K or N % 32 or get_gemm_mode() != "f16x3":
+    if K not in ROWLIN_K or N % 32 or get_gemm_mode() == "f32":
         return None
     rows = M * max(1, batch)
     if rows < ROWLIN_MIN_ROWS or M < 2048:
@@ -493,7 +495,7 @@ def _rowlin_route(w, M, N, K, ldw, batch):
 
 
 def rowlin_lookup(w, N, K, ldw=None):
-    return ROWLIN_TABLE.get((w.data_ptr(), N, K, K if ldw is None else ldw)) if get_gemm_mode() == "f16x3" else None
+    return ROWLIN_TABLE.get((w.data_ptr(), N, K, K if ldw is None else ldw)) if get_gemm_mode() != "f32" else None
 
 
 # Opt-in (TCE_SPLITK=1).  Measured at config 2: the skinny GEMMs live in the graph's side branches (text encoder

@@ -160,7 +160,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     def ln_(x, pre):
         return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
 
-    fused_ok = ops.get_gemm_mode() == "f16x3"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
+    fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
 
     def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
         """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
@@ -406,7 +406,7 @@ def _swin_backbone(model, frames, ar, sizes):
                                       C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
             gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
                     res_mode=RES_ADD)
-            pk = w.get(p + "mlp.ffn:pk") if ops.get_gemm_mode() == "f16x3" else None
+            pk = w.get(p + "mlp.ffn:pk") if ops.get_gemm_mode() != "f32" else None
             if pk is not None and ntok >= FFN_FUSED_MIN_ROWS:  # norm2 -> fc1 -> GELU -> fc2 -> +x in one launch
                 ops.ffn_fused(x, pk, w[p + "mlp.fc2.bias"], hid, ACT_GELU, M=ntok,
                               ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))

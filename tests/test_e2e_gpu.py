@@ -148,6 +148,8 @@ def test_video_swin_t_small_matches_reference(models):
                                             # long clips (DAVIS clip_size 32, inference_davis.py:209-213):
                                             # FTF token sequence T*8 = 256, IQT over 32 frames, MSDA with N = 32
                                             ("swin_t_p4w7", 32, 120, 216),
+                                            # the same chunk length at DAVIS resolution (480p): N*S = 273 k tokens
+                                            ("swin_t_p4w7", 32, 480, 854),
                                             # Video-Swin beyond one temporal window: T=19 pads to 24, temporal shift 4
                                             ("video_swin_t_p4w7", 19, 96, 160)])
 def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
@@ -350,3 +352,29 @@ def test_run_sharded_world1_on_gpu(models):
         assert torch.equal(out[i], fwd(clips[i]))
     empty = run_sharded(fwd, [], like=out[0])
     assert tuple(empty.shape) == (0, 3, H, W)
+
+
+def test_two_rank_gloo_rehearsal_on_one_device():
+    """bench.py's N > 1 control flow (clip sharding, harness kernel, asynchronous all-gather of uint8 masks, barrier,
+    max-over-ranks timing) with two processes sharing this box's one GPU: gloo for the collective, TCE_BENCH_ONE_DEVICE=1
+    puts both ranks on cuda:0.  Each rank is a fresh child process (nothing here has touched the GPU on its behalf)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TCE_BENCH_ONE_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--steps", "4", "--warmup", "2", "--frames", "2", "--height", "96", "--width", "128",
+                                       "--tokens", "8", "--no-cpu-baseline", "--no-roofline", "--no-variants"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["clips_per_step"] == 2 and line["value"] > 0
+    assert "all_gather(uint8 masks)" in line["config"]["parallelism"]
+    assert outs[1][0].strip() == ""   # only rank 0 prints

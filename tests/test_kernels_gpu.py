@@ -670,3 +670,35 @@ def test_msda_fused_lds_staged_is_bit_identical(ops):
     norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32)
     loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
     close(a.view(N, Lq, M * 32), O.msda_core(value, shapes, loc, aw), 1e-4, 1e-4)
+
+
+def test_single_pass_fp16_mode(ops):
+    """tce_set_gemm_mode(2) (BASELINE config 5's "fp16 MFMA"): one MFMA per product on operands rounded to nearest fp16,
+    fp32 accumulation -- in the tiled GEMM, the fused FFN and the token-stationary linear kernel alike.  Its error sits
+    where fp16 rounding of the operands puts it (~1e-3 of sum|a||b|), three orders above the default 3 x fp16 split."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 2000, 256, 256
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    ref = a.double() @ w.double().T + b.double()
+    scale = (a.double().abs() @ w.double().abs().T)
+    errs = {}
+    try:
+        for mode in ("f16x3", "f16"):
+            ops.set_gemm_mode(mode)
+            o1 = ops.gemm(dev(a), dev(w), bias=dev(b)).cpu().double()
+            pk = ops.rowlin_pack(dev(w))
+            o2 = torch.empty(M, N, device="cuda")
+            ops.rowlin(dev(a), pk, o2, M, N, K, K, N, bias=dev(b))
+            errs[mode] = (((o1 - ref).abs() / scale).max().item(), ((o2.cpu().double() - ref).abs() / scale).max().item())
+            w1, w2 = torch.randn(512, K, generator=g) / 16, torch.randn(K, 512, generator=g) / 22
+            fpk = ops.ffn_pack(dev(w1), dev(torch.zeros(512)), dev(w2))
+            of = torch.empty(M, K, device="cuda")
+            ops.ffn_fused(dev(a), fpk, dev(torch.zeros(K)), 512, ops.ACT_RELU, out=of)
+            rf = a.double() + torch.relu(a.double() @ w1.double().T) @ w2.double().T
+            errs[mode] += ((of.cpu().double() - rf).abs().max().item() / rf.abs().max().item(),)
+    finally:
+        ops.set_gemm_mode("f16x3")
+    print("errors (gemm, rowlin: relative to sum|a||b|; ffn: relative to max|out|):", errs)
+    for k in range(3):
+        assert errs["f16x3"][k] < 3e-6
+        assert 1e-5 < errs["f16"][k] < 2e-3
