@@ -409,13 +409,13 @@ class ReferFormer(nn.Module):
                 # beside the pixel decoder
                 ent = self._graphs.get(key)
                 if ent is None:
-                    st = (frames.clone(), ids.clone(), att.clone())
+                    st = (frames.clone(), ids.clone())
 
                     def text_fn(alloc):
                         return self._text_plan().forward(st[1], alloc)
 
                     ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames)
-                out = self._replay(key, ent, (frames, ids, att))
+                out = self._replay(key, ent, (frames, ids))
         ops.range_snapshot_async(frames.device)
         return out
 
@@ -463,8 +463,8 @@ class ReferFormer(nn.Module):
             if bool((att != 1).any()):
                 raise NotImplementedError("padded captions (B > 1) are not supported")
         else:  # token ids: every position is a token (no device read-back here: it would serialise consecutive clips)
-            ids, att = captions, torch.ones_like(captions)
-        return ids.to(device), att.to(device), (None if ids.is_cuda else ids)
+            ids, att = captions, None
+        return ids.to(device), (att.to(device) if att is not None else None), (None if ids.is_cuda else ids)
 
     def _text_plan(self):
         """RoBERTa on the HIP kernels (text_encoder.py); the HF module only owns the weights."""
