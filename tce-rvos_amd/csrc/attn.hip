@@ -5,6 +5,7 @@
 // in registers so softmax needs one rescale per tile and no cross-lane traffic.
 #include "common.h"
 #include "../../include/tce_rvos.h"
+#include "../../include/tce_rvos_debug.h"
 
 namespace {
 
@@ -278,6 +279,161 @@ __global__ void __launch_bounds__(64 * NW) mha_mfma_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Swin window attention on the matrix cores (exact fp32 MFMA, v_mfma_f32_32x32x2_f32), same index arithmetic as
+// window_attn_kernel above.  A workgroup = 4 waves = two (frame, window, head) items; the two waves of an item own
+// the query tiles 0..31 and 32..48 of the window and share its K / V (49 keys, zero-padded to 64) in LDS.  As in
+// mha_mfma_kernel the scores are computed transposed, S^T = K Q^T (keys on the MFMA rows, queries on the lanes): a lane
+// holds 2 x 16 key scores of ITS query in registers, the relative-position bias and the -100 shift mask are added
+// there, the softmax over the 49 keys is in-register (+ one cross-half shuffle), and P^T feeds O^T = V^T P^T as the B
+// operand without leaving the registers.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) window_attn_mfma_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ qkv_bias,
+                                                               const float* __restrict__ table, float* __restrict__ out,
+                                                               int T, int H, int W, int C, int nH, int shift, int nWy,
+                                                               int nWx, long long total) {
+  constexpr int WS = 7, NT = 49, KP = 33;
+  __shared__ float sK[2][64 * KP];
+  __shared__ __attribute__((aligned(16))) float sV[2][64 * HD];
+  __shared__ float sB[2][169];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int it = wave >> 1, qt = wave & 1;  // item slot inside the workgroup, query tile
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const long long item = (long long)blockIdx.x * 2 + it;  // ((t*nWy + wy)*nWx + wx)*nH + h
+  const bool active = item < total;
+  const int Hp = nWy * WS, Wp = nWx * WS;
+  int h = 0, wx = 0, wy = 0, t = 0;
+  if (active) {
+    long long r = item;
+    h = (int)(r % nH); r /= nH;
+    wx = (int)(r % nWx); r /= nWx;
+    wy = (int)(r % nWy); r /= nWy;
+    t = (int)r;
+  }
+  const int C3 = 3 * C;
+  // token j of the window -> source pixel (un-shifted, padded coordinates); false = padded token (qkv = bias)
+  auto src_of = [&](int j, int& ys, int& xs) {
+    const int yy = wy * WS + j / WS, xx = wx * WS + j % WS;
+    ys = yy + shift;
+    xs = xx + shift;
+    if (ys >= Hp) ys -= Hp;
+    if (xs >= Wp) xs -= Wp;
+    return ys < H && xs < W;
+  };
+  if (active) {
+    // the item's two waves (128 threads) stage K and V: 64 rows x 8 float4, rows >= 49 are zero
+    const int t2 = tid & 127;
+    for (int i = t2; i < 64 * 8; i += 128) {
+      const int j = i >> 3, d4 = i & 7;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (j < NT) {
+        int ys, xs;
+        if (src_of(j, ys, xs)) {
+          const float* p = qkv + (((long long)t * H + ys) * W + xs) * C3 + h * HD + d4 * 4;
+          kv = *reinterpret_cast<const f32x4*>(p + C);
+          vv = *reinterpret_cast<const f32x4*>(p + 2 * C);
+        } else {
+          kv = *reinterpret_cast<const f32x4*>(qkv_bias + C + h * HD + d4 * 4);
+          vv = *reinterpret_cast<const f32x4*>(qkv_bias + 2 * C + h * HD + d4 * 4);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sK[it][j * KP + d4 * 4 + c] = kv[c];
+      *reinterpret_cast<f32x4*>(&sV[it][j * HD + d4 * 4]) = vv;
+    }
+    for (int i = t2; i < 169; i += 128) sB[it][i] = table[i * nH + h];
+  }
+  __syncthreads();
+  if (!active) return;
+
+  const int qi = qt * 32 + l31;          // query index inside the window (>= 49: padding lane, never stored)
+  const int qc = min(qi, NT - 1);
+  int qys, qxs;
+  const bool real = src_of(qc, qys, qxs) && qi < NT;
+  const int iy = qc / WS, ix = qc % WS;
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  // B operand of S^T = K Q^T: lane holds q[d = 2s + lhi] * scale
+  float qreg[16];
+  {
+    int ys, xs;
+    const bool qreal = src_of(qc, ys, xs);
+    const float* p = qreal ? qkv + (((long long)t * H + ys) * W + xs) * C3 + h * HD : qkv_bias + h * HD;
+    float qrow[HD];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qrow[d4 * 4 + j] = v[j] * scale;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) qreg[s2] = lhi ? qrow[2 * s2 + 1] : qrow[2 * s2];
+  }
+  int rid = 0;  // region id of the -100 shift mask (built on the padded, shifted grid)
+  if (shift > 0) {
+    const int yy = wy * WS + iy, xx = wx * WS + ix;
+    const int ry = yy < Hp - WS ? 0 : (yy < Hp - shift ? 1 : 2);
+    const int rx = xx < Wp - WS ? 0 : (xx < Wp - shift ? 1 : 2);
+    rid = ry * 3 + rx;
+  }
+  f32x16 st[2];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[it][(kt * 32 + l31) * KP + 2 * s2 + lhi], qreg[s2], st[kt], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt * 32 + crow(r, lhi);  // key index inside the window
+      float a = -3.0e38f;
+      if (j < NT) {
+        const int jy = j / WS, jx = j % WS;
+        a = st[kt][r] + sB[it][(iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1)];
+        if (shift > 0) {
+          const int y2 = wy * WS + jy, x2 = wx * WS + jx;
+          const int ry = y2 < Hp - WS ? 0 : (y2 < Hp - shift ? 1 : 2);
+          const int rx = x2 < Wp - WS ? 0 : (x2 < Wp - shift ? 1 : 2);
+          if (ry * 3 + rx != rid) a += -100.0f;
+        }
+      }
+      st[kt][r] = a;
+      mx = fmaxf(mx, a);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pj = st[kt][r] > -1.0e38f ? __expf(st[kt][r] - mx) : 0.f;
+      st[kt][r] = pj;
+      l += pj;
+    }
+  l += __shfl_xor(l, 32, 64);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  // O^T[d][q] += V^T[d][key] P^T[key][q] : k-step r pairs keys crow(r,0), crow(r,1)
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[it][(kt * 32 + crow(r, lhi)) * HD + l31], st[kt][r], o, 0, 0, 0);
+  if (real) {
+    const float inv = 1.0f / l;
+    float* po = out + (((long long)t * H + qys) * W + qxs) * C + h * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {  // registers 4g..4g+3 are 4 consecutive d: d = 8g + 4*lhi + (0..3)
+      f32x4 v = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(po + 8 * g4 + 4 * lhi) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Video-Swin 3-D window attention (video_swin_transformer.py:71-84,138-169,215-249,316-329).
 // One workgroup per (window, head); the window's K/V (<= 8*7*7 = 392 tokens x 32) and this head's column of
 // the relative-position table live in LDS for the whole workgroup.  Reference quirks reproduced:
@@ -431,6 +587,12 @@ __global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restr
 
 }  // namespace
 
+static int g_window_attn_mfma = 1;  // tuning aid (tce_debug_window_attn_set_mfma): 0 = the VALU kernel
+extern "C" int tce_debug_window_attn_set_mfma(int32_t on) {
+  g_window_attn_mfma = on;
+  return TCE_OK;
+}
+
 extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out,
                                    int32_t T, int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shift,
                                    tceStream stream) {
@@ -442,8 +604,12 @@ extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, cons
                 "tce_window_attn_f32: pointers must be 16-byte aligned");
   const int nWy = (H + 6) / 7, nWx = (W + 6) / 7;
   const long long total = (long long)T * nWy * nWx * nH;
-  hipLaunchKernelGGL(window_attn_kernel, dim3(tce_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
-                     bias_table, out, T, H, W, C, nH, shift, nWy, nWx, total);
+  if (g_window_attn_mfma)
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(tce_cdiv(total, 2)), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
+                       bias_table, out, T, H, W, C, nH, shift, nWy, nWx, total);
+  else
+    hipLaunchKernelGGL(window_attn_kernel, dim3(tce_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
+                       bias_table, out, T, H, W, C, nH, shift, nWy, nWx, total);
   TCE_CHECK_LAUNCH("tce_window_attn_f32");
   return TCE_OK;
 }

@@ -187,6 +187,15 @@ def test_window_attention(ops, T, H, W, nH, shift):
     out = ops.window_attn(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W, C,
                           nH, shift)
     close(out, ref, 1e-4, 1e-4)
+    # the VALU form of the same op (kept as the A/B partner of the matrix-core kernel)
+    from tce_rvos_amd._lib import lib
+    lib().tce_debug_window_attn_set_mfma(0)
+    try:
+        out2 = ops.window_attn(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
+                               C, nH, shift)
+    finally:
+        lib().tce_debug_window_attn_set_mfma(1)
+    close(out2, ref, 1e-4, 1e-4)
 
 
 @pytest.mark.parametrize("T,H,W,C", [(2, 18, 25, 96), (1, 9, 13, 192), (1, 5, 7, 384), (1, 4, 4, 32)])
