@@ -297,6 +297,7 @@ def main():
         line.update(variants)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0's extra (collective-free) passes are done: leave together
         dist.destroy_process_group()
 
 
