@@ -260,6 +260,35 @@ int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K);
 int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream);
 int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream);
 
+/* Text cross-attention of a token tensor against L <= 32 text keys as ONE token-stationary launch (csrc/chain.hip):
+ *     out = LN?( res (+|*) ( MHA(q = x + a2, k, v) W_o^T + b_o ) )          8 heads x 32 channels, 32 keys per head
+ * (VisionLanguageBlock's multihead_attn + residual + norm2, segmentation.py:366-371; VisionLanguageFusionModule,
+ * segmentation.py:455-464 with res_mode 2 and no LayerNorm).  With few keys the per-head score is linear in x:
+ *     score_h[t,j] = (x+a2)[t,:] . W1[h*32+j,:] + b1[h*32+j],   W1 = scale * k_h W_q,h,  b1 = scale * k_h . b_q,h
+ *     out[t,:]     = sum_h softmax_j(score_h[t,:]) . W2[:, h*32+j] + b_o,   W2[:, h*32+j] = W_o,h v_h[j]
+ * i.e. linear1 -> (softmax over each group of 32 hidden units) -> linear2: the fused FFN kernel with a grouped softmax
+ * as its activation; q, the scores and the per-head outputs never exist in memory.  Per clip:
+ *   tce_xattn_prepare_f32  k, v [L,256] (projected keys / values), wqT_ext [257,256] = scale * [W_q^T ; b_q] (static),
+ *                          wo [256,256] -> W1 [256,256], b1 [256] (-1e30 for key slots >= L), W2 [256,256];
+ *   tce_ffn_pack_f32(W1, b1, W2, packed, 256, 256) -> the weight stream;   tce_xattn_fused_f32 -> the launch.
+ * a2 / a2_rows / batch strides as in tce_rowlin_f32; res NULL = x; res_mode 1 add | 2 multiply; out may alias x. */
+typedef struct {
+  const float* x;
+  const float* a2;
+  const void* packed;
+  const float* bo;
+  const float* res;
+  float* out;
+  const float *g_out, *be_out;
+  int64_t ldx, lda2, ldres, ldo;
+  int64_t sX, sRes, sOut;
+  int32_t M, batch, a2_rows, res_mode;
+  float eps_out;
+} tceXattnArgs;
+int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
+                          float* W2, int32_t L, tceStream stream);
+int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream);
+
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */
 int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);

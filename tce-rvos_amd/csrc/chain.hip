@@ -105,7 +105,7 @@ constexpr int WT_BYTES = 32 * WT_PITCH * 4;  // 4608 bytes per wave
 // x[32 tokens, K] (+ a2, LayerNorm) -> fp16 hi/lo B fragments (lane (r, hf) holds k = 16s + 8hf + 0..7 of token r).
 // a2: optional addend with row pitch lda2; a2_rows > 0: its row index is (token % a2_rows) (a position map shared by
 // all frames).  g_in / be_in: optional LayerNorm over K applied to (x + a2).
-template <int K>
+template <int K, bool HAS_A2 = true>
 __device__ __forceinline__ void load_x_frags(const float* __restrict__ x, const long long ldx,
                                              const float* __restrict__ a2, const long long lda2, const int a2_rows,
                                              const int m0, const int M, float* __restrict__ wt, const int lane,
@@ -122,7 +122,7 @@ __device__ __forceinline__ void load_x_frags(const float* __restrict__ x, const 
     const float* px = x + (long long)row * ldx + cp;
 #pragma unroll
     for (int q = 0; q < NP; ++q) v[q][i] = *reinterpret_cast<const f32x4*>(px + 32 * q);
-    if (a2) {
+    if (HAS_A2 && a2) {
       const float* pa = a2 + (long long)(a2_rows > 0 ? row % a2_rows : row) * lda2 + cp;
 #pragma unroll
       for (int q = 0; q < NP; ++q) v[q][i] += *reinterpret_cast<const f32x4*>(pa + 32 * q);
@@ -303,6 +303,11 @@ struct FfnArgs {
   const float *g_in, *be_in, *g_out, *be_out;
   float* out;
   long long ldx, ldo;
+  // optional: addend to the first product's input only (position map; a2_rows > 0: row index modulo a2_rows), a residual
+  // other than x (NULL = x) combined by res_mode (1 add, 2 multiply), batch strides (grid.y) in floats
+  const float *a2, *res;
+  long long lda2, ldres, sX, sRes, sOut;
+  int a2_rows, res_mode;
   int M, NI;  // NI = hidden/32 + 1 iterations
   float eps_in, eps_out;
   int* range_flag;  // tce_set_range_flag: set when a hidden or an output value leaves the fp16 range of the split
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   // every read of `smem` as undefined and deletes it.  This store never executes (NI >= 2 always).
   if (p.NI < 0) reinterpret_cast<u32x4*>(smem)[tid] = u32x4{0u, 0u, 0u, 0u};
 
-  long long* const stamps = (g_ffn_stamps && blockIdx.x < 1024 && tid == 0) ? g_ffn_stamps + blockIdx.x * 8 : nullptr;
+  long long* const stamps = (g_ffn_stamps && blockIdx.x < 1024 && blockIdx.y == 0 && tid == 0) ? g_ffn_stamps + blockIdx.x * 8 : nullptr;
   if (stamps) {
     stamps[0] = (long long)__builtin_amdgcn_s_memtime();
     stamps[4] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -349,9 +354,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 
   // ---- x: 32 tokens x C -> fp16 hi/lo B fragments, full-line loads staged through this wave's private tile
   const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
+  const float* const xb = p.x + blockIdx.y * p.sX;
+  const float* const resb = p.res ? p.res + blockIdx.y * p.sRes : xb;
+  const long long ldres = p.res ? p.ldres : p.ldx;
+  float* const outb = p.out + blockIdx.y * p.sOut;
   float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<C>(p.x, p.ldx, nullptr, 0, 0, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
+  load_x_frags<C, ACT == 3>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
 
   f32x16 oacc[NT];
 #pragma unroll
@@ -416,6 +425,24 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
           }
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hh0, oacc[t], 0, 0, 0);
         }
+        if (ACT == 3 && j == 0) {
+          // "activation" = softmax over the chunk's 32 rows (the 32 keys of one attention head) per token: 16 of them
+          // in this lane's registers, 16 in lane ^ 32.  In place; the pair loop below then only splits.
+          float mx = hacc[0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, hacc[i]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            hacc[i] = __expf(hacc[i] - mx);
+            sum += hacc[i];
+          }
+          sum += __shfl_xor(sum, 32, 64);
+          const float inv = 1.0f / sum;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hacc[i] *= inv;
+        }
         // activation + hi/lo split of value pairs [8j/(2NT), 8(j+1)/(2NT)) of this chunk, spread over the 2NT steps
 #pragma unroll
         for (int q = (8 * j) / (2 * NT); q < (8 * (j + 1)) / (2 * NT); ++q) {
@@ -470,13 +497,18 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   {
     ResTile rt[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(p.x, p.ldx, m0, p.M, 32 * t, lane);
+    for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(resb, ldres, m0, p.M, 32 * t, lane);
+    if (p.res_mode == 2) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
+      for (int t = 0; t < NT; ++t) tile_bias_res<2>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
+    }
   }
   if (p.g_out) rows_layernorm<NT>(oacc, p.g_out, p.be_out, p.eps_out, hf);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) tile_store(oacc[t], p.out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
+  for (int t = 0; t < NT; ++t) tile_store(oacc[t], outb, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
   tce_range_report(p.range_flag, amax);
   if (stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -787,10 +819,55 @@ inline int ffn_pieces(int C) {
 inline long long ffn_units(int C, int Hd) { return (long long)(Hd / 32 + 2) * ffn_pieces(C) * 64; }  // + 1 block of padding
 
 template <int C, int WAVES>
-void ffn_launch(const FfnArgs& a, int act, hipStream_t s) {
-  const dim3 grid(tce_cdiv(a.M, 32 * WAVES)), block(64 * WAVES);
+void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
+  const dim3 grid(tce_cdiv(a.M, 32 * WAVES), batch), block(64 * WAVES);
   if (act == 1) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 2>), grid, block, 0, s, a);
+  else if (act == 2) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 2>), grid, block, 0, s, a);
+}
+
+// Text cross-attention as an FFN-shaped chain (see tce_xattn_prepare_f32 in the header): folds the per-clip key / value
+// rows of every head into the two weight matrices.  One thread per output element, exact fp32 FMAs.
+__global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ wqT, const float* __restrict__ wo,
+                                                            float* __restrict__ W1, float* __restrict__ b1,
+                                                            float* __restrict__ W2, const int L) {
+  constexpr int C = 256, HD = 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < C * C) {  // W1[h*32 + j][i] = sum_c k[j][h*32 + c] * wqT[i][h*32 + c]
+    const int r = idx / C, i = idx - r * C, h = r / HD, j = r - h * HD;
+    float a = 0.f;
+    if (j < L) {
+      const f32x4* kp = reinterpret_cast<const f32x4*>(k + j * C + h * HD);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(wqT + (long long)i * C + h * HD);
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const f32x4 kv = kp[c4], wv = wp[c4];
+        a = fmaf(kv[0], wv[0], a); a = fmaf(kv[1], wv[1], a); a = fmaf(kv[2], wv[2], a); a = fmaf(kv[3], wv[3], a);
+      }
+    }
+    W1[idx] = a;
+  } else if (idx < 2 * C * C) {  // W2[n][h*32 + j] = sum_c wo[n][h*32 + c] * v[j][h*32 + c]
+    const int e = idx - C * C, n = e / C, r = e - n * C, h = r / HD, j = r - h * HD;
+    float a = 0.f;
+    if (j < L) {
+      const f32x4* vp = reinterpret_cast<const f32x4*>(v + j * C + h * HD);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(wo + (long long)n * C + h * HD);
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const f32x4 vv = vp[c4], wv = wp[c4];
+        a = fmaf(vv[0], wv[0], a); a = fmaf(vv[1], wv[1], a); a = fmaf(vv[2], wv[2], a); a = fmaf(vv[3], wv[3], a);
+      }
+    }
+    W2[e] = a;
+  } else if (idx < 2 * C * C + C) {  // b1[h*32 + j] = sum_c k[j][h*32 + c] * wqT[256][h*32 + c]; padded keys: -inf
+    const int r = idx - 2 * C * C, h = r / HD, j = r - h * HD;
+    float a = -1.0e30f;
+    if (j < L) {
+      a = 0.f;
+      for (int c = 0; c < HD; ++c) a = fmaf(k[j * C + h * HD + c], wqT[(long long)C * C + h * HD + c], a);
+    }
+    b1[r] = a;
+  }
 }
 
 }  // namespace
@@ -826,8 +903,8 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   TCE_CHECK_ARG((!g_in || (be_in && tce_aligned16(g_in) && tce_aligned16(be_in))) &&
                     (!g_out || (be_out && tce_aligned16(g_out) && tce_aligned16(be_out))),
                 "tce_ffn_fused_f32: LayerNorm gamma/beta must come in pairs, 16-byte aligned");
-  FfnArgs a;
-  a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2;
+  FfnArgs a = {};
+  a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2; a.res_mode = 1;
   a.g_in = g_in; a.be_in = be_in; a.g_out = g_out; a.be_out = be_out;
   a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
   hipStream_t s = (hipStream_t)stream;
@@ -836,6 +913,43 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   else if (C == 128) ffn_launch<128, 8>(a, act, s);
   else ffn_launch<96, 8>(a, act, s);
   TCE_CHECK_LAUNCH("tce_ffn_fused_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
+                                     float* W2, int32_t L, tceStream stream) {
+  TCE_CHECK_ARG(k && v && wqT_ext && wo && W1 && b1 && W2, "tce_xattn_prepare_f32: null pointer");
+  TCE_CHECK_ARG(L >= 1 && L <= 32, "tce_xattn_prepare_f32: 1 <= L <= 32 keys (got %d)", L);
+  TCE_CHECK_ARG(tce_aligned16(k) && tce_aligned16(v) && tce_aligned16(wqT_ext) && tce_aligned16(wo),
+                "tce_xattn_prepare_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(xattn_prepare_kernel, dim3(tce_cdiv(2 * 256 * 256 + 256, 256)), dim3(256), 0, (hipStream_t)stream, k, v,
+                     wqT_ext, wo, W1, b1, W2, L);
+  TCE_CHECK_LAUNCH("tce_xattn_prepare_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
+  TCE_CHECK_ARG(args != nullptr, "tce_xattn_fused_f32: null args");
+  const tceXattnArgs& q = *args;
+  TCE_CHECK_ARG(q.M > 0 && q.x && q.packed && q.bo && q.out, "tce_xattn_fused_f32: null pointer or M <= 0");
+  TCE_CHECK_ARG(q.res_mode == 1 || q.res_mode == 2, "tce_xattn_fused_f32: res_mode must be 1 (add) or 2 (multiply)");
+  TCE_CHECK_ARG(q.ldx >= 256 && q.ldo >= 256 && q.ldx % 4 == 0 && q.ldo % 4 == 0 && (!q.res || (q.ldres >= 256 && q.ldres % 4 == 0)) &&
+                    (!q.a2 || (q.lda2 >= 256 && q.lda2 % 4 == 0)) && q.sX % 4 == 0 && q.sRes % 4 == 0 && q.sOut % 4 == 0,
+                "tce_xattn_fused_f32: bad row pitch / batch stride");
+  TCE_CHECK_ARG(tce_aligned16(q.x) && tce_aligned16(q.out) && tce_aligned16(q.packed) && tce_aligned16(q.bo) &&
+                    (!q.a2 || tce_aligned16(q.a2)) && (!q.res || tce_aligned16(q.res)),
+                "tce_xattn_fused_f32: pointers must be 16-byte aligned");
+  TCE_CHECK_ARG(!q.g_out || (q.be_out && tce_aligned16(q.g_out) && tce_aligned16(q.be_out)),
+                "tce_xattn_fused_f32: LayerNorm gamma/beta must come in pairs, 16-byte aligned");
+  FfnArgs a = {};
+  a.x = q.x; a.wpk = (const unsigned char*)q.packed; a.b2 = q.bo; a.g_out = q.g_out; a.be_out = q.be_out; a.out = q.out;
+  a.ldx = q.ldx; a.ldo = q.ldo; a.a2 = q.a2; a.lda2 = q.lda2; a.a2_rows = q.a2_rows; a.res = q.res; a.ldres = q.ldres;
+  a.res_mode = q.res_mode; a.sX = q.sX; a.sRes = q.sRes; a.sOut = q.sOut;
+  a.M = q.M; a.NI = 256 / 32 + 1; a.eps_out = q.eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  const int batch = q.batch > 0 ? q.batch : 1;
+  const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
+  hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3>), grid, block, 0, (hipStream_t)stream, a);
+  TCE_CHECK_LAUNCH("tce_xattn_fused_f32");
   return TCE_OK;
 }
 

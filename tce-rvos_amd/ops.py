@@ -534,9 +534,10 @@ def select_masks(pred_logits, pred_masks, out_hw, threshold=0.5):
     return out, best
 
 
-def ffn_pack(w1, b1, w2):
+def ffn_pack(w1, b1, w2, out=None):
     """Packs nn.Linear weights W1 [Hd,C], b1 [Hd], W2 [C,Hd] into the fused-FFN stream (csrc/chain.hip): fp16 hi/lo
-    planes in MFMA-fragment order.  Done once per load_state_dict."""
+    planes in MFMA-fragment order.  Done once per load_state_dict (static weights) or once per clip into an arena
+    buffer `out` (the text cross-attention's folded weights)."""
     _chk(w1, "w1")
     _chk(w2, "w2")
     Hd, Cn = w1.shape
@@ -545,7 +546,10 @@ def ffn_pack(w1, b1, w2):
     nbytes = lib().tce_ffn_packed_bytes(Cn, Hd)
     if nbytes < 0:
         raise ValueError(f"ffn_pack: unsupported shape C={Cn} hidden={Hd}")
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    elif out.numel() < nbytes:
+        raise ValueError("ffn_pack: out buffer too small")
     check(lib().tce_ffn_pack_f32(w1.contiguous().data_ptr(), b1.contiguous().data_ptr() if b1 is not None else None,
                                  w2.contiguous().data_ptr(), out.data_ptr(), Cn, Hd, _stream()), "tce_ffn_pack_f32")
     return out
@@ -644,4 +648,57 @@ def rowlin(x, pk, out, M, N, K, ldx, ldo, bias=None, a2=None, lda2=0, a2_rows=0,
     go()
     e1.record()
     GEMM_PROFILE.append((f"rowlin_kernel<{K}", False, 2.0 * M * N * K * batch, e0, e1))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Text cross-attention as one token-stationary launch (csrc/chain.hip: tce_xattn_prepare_f32 / tce_xattn_fused_f32):
+# with <= 32 keys the per-head scores are linear in the query rows, so q-projection -> attention -> out-projection ->
+# residual -> LayerNorm is the fused FFN kernel with a grouped softmax as its activation.
+# ---------------------------------------------------------------------------------------------------------------
+XATTN_MIN_ROWS = int(os.environ.get("TCE_XATTN_MIN_ROWS", 4000))
+
+
+def xattn_static(wq, bq, scale=32 ** -0.5):
+    """Static half of the fold, done at pack time: scale * [W_q^T ; b_q] as a contiguous [257, 256] tensor."""
+    return (torch.cat([wq.t(), bq[None]], 0) * scale).contiguous()
+
+
+def xattn_pack(k, v, wqT_ext, wo, L, alloc):
+    """Per clip: folds the projected keys / values [L,256] of the 8 heads into W1, b1, W2 and packs the weight stream."""
+    _chk(k, "k")
+    _chk(v, "v")
+    W1, b1, W2 = alloc(256, 256), alloc(256), alloc(256, 256)
+    check(lib().tce_xattn_prepare_f32(k.data_ptr(), v.data_ptr(), wqT_ext.data_ptr(), wo.data_ptr(), W1.data_ptr(), b1.data_ptr(),
+                                      W2.data_ptr(), L, _stream()), "tce_xattn_prepare_f32")
+    nbytes = lib().tce_ffn_packed_bytes(256, 256)
+    pk = alloc(nbytes, dtype=torch.uint8)
+    return ffn_pack(W1, b1, W2, out=pk)
+
+
+def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_mode=RES_ADD, ln_out=None, eps_out=1e-5,
+                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256):
+    from ._lib import XattnArgs
+    q = XattnArgs()
+    q.x, q.packed, q.bo, q.out = x.data_ptr(), pk.data_ptr(), bo.data_ptr(), out.data_ptr()
+    q.M, q.batch, q.res_mode, q.eps_out = M, batch, res_mode, eps_out
+    q.ldx, q.ldo, q.ldres, q.lda2 = ldx, ldo, ldres, lda2
+    q.sX, q.sRes, q.sOut = sX, sRes, sOut
+    if a2 is not None:
+        q.a2, q.a2_rows = a2.data_ptr(), a2_rows
+    if res is not None:
+        q.res = res.data_ptr()
+    if ln_out is not None:
+        q.g_out, q.be_out = ln_out[0].data_ptr(), ln_out[1].data_ptr()
+
+    def go():
+        check(lib().tce_xattn_fused_f32(C.byref(q), _stream()), "tce_xattn_fused_f32")
+    if GEMM_PROFILE is None:
+        go()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    GEMM_PROFILE.append(("xattn(ffn_fused_kernel<256,4,3>", False, 4.0 * M * 256 * 256 * batch, e0, e1))
     return out

@@ -86,43 +86,53 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     ar.reset()
     if side_arena is not None:
         side_arena.reset()
-    text_fork = None
-    if callable(text):
-        text_fork = _Fork(side_stream)
-        with text_fork:
-            text = text((side_arena if side_arena is not None else ar).alloc)
-    text_hidden, text_pooled = text
     A = ar.alloc
     sc = model._shape_consts(T, H0, W0, dev)
     sizes, lvl_sizes, S, starts = sc["sizes"], sc["lvl_sizes"], sc["S"], sc["starts"]
     Q = cfg.num_queries
     ff = cfg.dim_feedforward
 
+    # ------------------------------------------------------------------ text stage (tce_rvos.py:406-424, FeatureResizer
+    # :616-635) and everything that depends on the text alone: the projected keys / values of the five text
+    # cross-attention sites and their folded weight streams (csrc/chain.hip, tce_xattn_fused_f32).  With a side stream it
+    # is a parallel graph branch beside the backbone; its buffers live in the side arena until the end of the clip.
+    tA = (side_arena if side_arena is not None else ar).alloc
+    text_fork = _Fork(side_stream)
+    with text_fork:
+        text_hidden, text_pooled = text(tA) if callable(text) else text
+        L = text_hidden.shape[0]
+        tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+        text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
+        tmp = _lin(tA, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+        sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
+        text_pos = model._text_pos(L, dev)
+        xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
+
+        def text_site(pre, rows):
+            """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows."""
+            k = tA(L, D)
+            gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
+            v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA) \
+                if xattn_ok and rows >= ops.XATTN_MIN_ROWS else None
+            return k, v, pk
+
+        fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1])
+        vl_sites = {}
+        if cfg.vlblock:
+            for stage in (4, 3, 2, 1):
+                h_, w_ = sizes[stage - 1]
+                vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_)
+
     _stage("start")
     # ------------------------------------------------------------------ backbone
     feats = (_resnet_backbone if cfg.is_resnet else _swin_backbone)(model, frames, ar, sizes)
 
     _stage("backbone")
-    # ------------------------------------------------------------------ text (FeatureResizer :616-635)
-    if text_fork is not None:
-        text_fork.join()
-    L = text_hidden.shape[0]
-    tmp = _lin(A, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-    text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=A(L, D))
-    tmp = _lin(A, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-    sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=A(1, D))
-    text_pos = model._text_pos(L, dev)
-
-    def text_kv(pre):
-        k = A(L, D)
-        gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
-        v = _lin(A, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
-        return k, v
-
-    _stage("text join + resizer")
+    text_fork.join()
+    _stage("text join")
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
     src = A(T * S, D)  # [T, S, 256]: the encoder sequence
-    fk, fv = text_kv("fusion_module.multihead_attn.")
     chs = cfg.num_channels
     for l in range(4):
         h, ww = lvl_sizes[l]
@@ -140,6 +150,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                                       ws=A(sk * T * h * ww * D) if sk > 1 else None)
             assert (ho, wo) == (h, ww)
         s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
+        if fpk is not None and T * hw >= ops.XATTN_MIN_ROWS:
+            # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]
+            ops.xattn_fused(s, fpk, w["fusion_module.multihead_attn.out_proj.bias"], hw, src[starts[l]:], res_mode=RES_MUL,
+                            batch=T, sX=hw * D, sRes=hw * D, sOut=S * D)
+            ar.release(m0)
+            continue
         q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
         att = A(T * hw, D)
         ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
@@ -318,7 +334,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
-    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_)
     dec_fork.join()
 
     _stage("pixel decoder")
@@ -474,7 +490,7 @@ def _resnet_backbone(model, frames, ar, sizes):
     return feats
 
 
-def _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, ffn, ln_):
+def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_):
     """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level."""
     cfg, w = model.cfg, model._packed
     A = ar.alloc
@@ -532,14 +548,19 @@ def _pixel_decoder(model, ar, sc, feats, memory, text, text_pos, text_kv, T, L, 
             # text cross-attention (:366-371)
             pre = bp + "multihead_attn."
             m1 = ar.mark()
-            tk, tv = text_kv(pre)
-            q = A(T * hw, D)
-            gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
-                    sA2=0, sC=hw * D)
-            att = A(T * hw, D)
-            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
-                         w[bp + "norm2.bias"])
+            tk, tv, pk = vl_sites[stage]
+            if pk is not None:
+                # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
+                ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
+                                ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
+            else:
+                q = A(T * hw, D)
+                gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
+                        sA2=0, sC=hw * D)
+                att = A(T * hw, D)
+                ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+                _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
+                             w[bp + "norm2.bias"])
             ar.release(m1)
             ffn(tgt, T * hw, bp, norm=bp + "norm3")
         # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU

@@ -711,3 +711,49 @@ def test_single_pass_fp16_mode(ops):
     for k in range(3):
         assert errs["f16x3"][k] < 3e-6
         assert 1e-5 < errs["f16"][k] < 2e-3
+
+
+@pytest.mark.parametrize("M,L,mode", [(18000, 32, "add_ln"), (4600, 11, "add_ln"), (301, 32, "mul"), (7200, 20, "mul_batched")])
+def test_xattn_fused(ops, M, L, mode):
+    """Text cross-attention (q-proj -> 8-head attention over L <= 32 keys -> out-proj -> residual -> LayerNorm) as one
+    token-stationary launch against nn.MultiheadAttention semantics in torch fp32 (segmentation.py:366-371 with a
+    position addend on the query, :455-464 with the multiplicative residual)."""
+    g = torch.Generator().manual_seed(M + L)
+    Cn = 256
+    x = torch.randn(M, Cn, generator=g)
+    pos = torch.randn(M // 5 if M % 5 == 0 else M, Cn, generator=g) * 0.5
+    text = torch.randn(L, Cn, generator=g)
+    mha = torch.nn.MultiheadAttention(Cn, 8)
+    with torch.no_grad():
+        for p_ in mha.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.06 if p_.dim() == 2 else 0.2))
+    Wq, Wk, Wv = mha.in_proj_weight.detach().chunk(3, 0)
+    bq, bk, bv = mha.in_proj_bias.detach().chunk(3, 0)
+    k = F.linear(text, Wk, bk)
+    v = F.linear(text, Wv, bv)
+    gam, bet = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    rows = pos.shape[0]
+    qin = x + pos[torch.arange(M) % rows] if mode == "add_ln" else x
+    with torch.no_grad():
+        att = mha(qin[:, None], text[:, None], text[:, None])[0][:, 0]
+    if mode == "add_ln":
+        ref = F.layer_norm(x + att, (Cn,), gam, bet, 1e-5)
+    else:
+        ref = x * att
+    ar = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device="cuda")
+    wqT = ops.xattn_static(dev(Wq), dev(bq))
+    pk = ops.xattn_pack(dev(k), dev(v), wqT, dev(mha.out_proj.weight.detach()), L, ar)
+    xd = dev(x)
+    out = torch.empty_like(xd)
+    bo = dev(mha.out_proj.bias.detach())
+    if mode == "add_ln":
+        ops.xattn_fused(xd, pk, bo, M, out, a2=dev(pos), a2_rows=rows if rows != M else 0, ln_out=(dev(gam), dev(bet)))
+    elif mode == "mul":
+        ops.xattn_fused(xd, pk, bo, M, out, res_mode=ops.RES_MUL)
+    else:  # frame-batched: 4 frames of M/4 rows written into a wider destination with a per-frame stride
+        nb, mb = 4, M // 4
+        wide = torch.zeros(nb, mb + 50, Cn, device="cuda")
+        ops.xattn_fused(xd, pk, bo, mb, wide, res_mode=ops.RES_MUL, batch=nb, sX=mb * Cn, sRes=mb * Cn, sOut=(mb + 50) * Cn)
+        out = wide[:, :mb].reshape(M, Cn)
+        assert float(wide[:, mb:].abs().max()) == 0.0
+    close(out, ref, 3e-4, 3e-4)
