@@ -227,6 +227,9 @@ int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
 int64_t tce_ffn_packed_bytes(int32_t C, int32_t Hd);
 int tce_ffn_pack_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
                      tceStream stream);
+/* `batch` independent weight sets, contiguous ([batch][Hd,C], [batch][Hd], [batch][C,Hd]) -> contiguous streams */
+int tce_ffn_pack_batched_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
+                             int32_t batch, tceStream stream);
 int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in,
                       const float* be_in, float eps_in, const float* g_out, const float* be_out, float eps_out,
                       float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act, tceStream stream);
@@ -260,17 +263,21 @@ int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K);
 int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream);
 int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream);
 
-/* Text cross-attention of a token tensor against L <= 32 text keys as ONE token-stationary launch (csrc/chain.hip):
- *     out = LN?( res (+|*) ( MHA(q = x + a2, k, v) W_o^T + b_o ) )          8 heads x 32 channels, 32 keys per head
+/* Cross-attention of a token tensor against a SHORT key sequence as ONE token-stationary launch (csrc/chain.hip):
+ *     out = LN?( res (+|*) ( MHA(q = x + a2, k, v) W_o^T + b_o ) )          8 heads x 32 channels, `group` key slots
+ * group 32: the L <= 32 text keys (VisionLanguageBlock / fusion module); group 8: the f_token = 8 frame tokens of
+ * FrameTokenLayer's pixel <- token attention (tce_deformable_transformer.py:480-484), keys / values per frame (batch).
  * (VisionLanguageBlock's multihead_attn + residual + norm2, segmentation.py:366-371; VisionLanguageFusionModule,
  * segmentation.py:455-464 with res_mode 2 and no LayerNorm).  With few keys the per-head score is linear in x:
  *     score_h[t,j] = (x+a2)[t,:] . W1[h*32+j,:] + b1[h*32+j],   W1 = scale * k_h W_q,h,  b1 = scale * k_h . b_q,h
  *     out[t,:]     = sum_h softmax_j(score_h[t,:]) . W2[:, h*32+j] + b_o,   W2[:, h*32+j] = W_o,h v_h[j]
  * i.e. linear1 -> (softmax over each group of 32 hidden units) -> linear2: the fused FFN kernel with a grouped softmax
  * as its activation; q, the scores and the per-head outputs never exist in memory.  Per clip:
- *   tce_xattn_prepare_f32  k, v [L,256] (projected keys / values), wqT_ext [257,256] = scale * [W_q^T ; b_q] (static),
- *                          wo [256,256] -> W1 [256,256], b1 [256] (-1e30 for key slots >= L), W2 [256,256];
- *   tce_ffn_pack_f32(W1, b1, W2, packed, 256, 256) -> the weight stream;   tce_xattn_fused_f32 -> the launch.
+ *   tce_xattn_prepare_f32  k, v [batch][L,256] (projected keys / values), wqT_ext [257,256] = scale * [W_q^T ; b_q]
+ *                          (static), wo [256,256] -> per batch entry W1 [8*group,256], b1 [8*group] (-1e30 for key
+ *                          slots >= L), W2 [256,8*group];
+ *   tce_ffn_pack_batched_f32 with W1, b1, W2, 256, 8*group, batch -> the weight stream(s);
+ *   tce_xattn_fused_f32 -> the launch (sW = bytes between the streams of consecutive batch entries, 0 = shared).
  * a2 / a2_rows / batch strides as in tce_rowlin_f32; res NULL = x; res_mode 1 add | 2 multiply; out may alias x. */
 typedef struct {
   const float* x;
@@ -281,12 +288,12 @@ typedef struct {
   float* out;
   const float *g_out, *be_out;
   int64_t ldx, lda2, ldres, ldo;
-  int64_t sX, sRes, sOut;
-  int32_t M, batch, a2_rows, res_mode;
+  int64_t sX, sRes, sOut, sW;
+  int32_t M, batch, a2_rows, res_mode, group;
   float eps_out;
 } tceXattnArgs;
 int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
-                          float* W2, int32_t L, tceStream stream);
+                          float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream);
 int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream);
 
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */

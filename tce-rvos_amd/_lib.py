@@ -36,8 +36,8 @@ class XattnArgs(C.Structure):
     _fields_ = [("x", c_f), ("a2", c_f), ("packed", c_f), ("bo", c_f), ("res", c_f), ("out", c_f),
                 ("g_out", c_f), ("be_out", c_f),
                 ("ldx", i64), ("lda2", i64), ("ldres", i64), ("ldo", i64),
-                ("sX", i64), ("sRes", i64), ("sOut", i64),
-                ("M", i32), ("batch", i32), ("a2_rows", i32), ("res_mode", i32), ("eps_out", f32)]
+                ("sX", i64), ("sRes", i64), ("sOut", i64), ("sW", i64),
+                ("M", i32), ("batch", i32), ("a2_rows", i32), ("res_mode", i32), ("group", i32), ("eps_out", f32)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol of include/tce_rvos.h (tests check this)
@@ -81,7 +81,8 @@ SIGNATURES = {
     "tce_ffn_packed_bytes": (i64, [i32, i32]),
     "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tce_ffn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f]),
-    "tce_xattn_prepare_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f]),
+    "tce_xattn_prepare_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
+    "tce_ffn_pack_batched_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_xattn_fused_f32": (i32, [C.POINTER(XattnArgs), c_f]),
     "tce_rowlin_packed_bytes": (i64, [i32, i32]),
     "tce_rowlin_pack_f32": (i32, [c_f, i64, c_f, i32, i32, c_f]),

@@ -306,7 +306,7 @@ struct FfnArgs {
   // optional: addend to the first product's input only (position map; a2_rows > 0: row index modulo a2_rows), a residual
   // other than x (NULL = x) combined by res_mode (1 add, 2 multiply), batch strides (grid.y) in floats
   const float *a2, *res;
-  long long lda2, ldres, sX, sRes, sOut;
+  long long lda2, ldres, sX, sRes, sOut, sW;  // sW: bytes between the weight streams of consecutive batch entries
   int a2_rows, res_mode;
   int M, NI;  // NI = hidden/32 + 1 iterations
   float eps_in, eps_out;
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   // this wave's pieces are wave, wave + WAVES, ... of every block, and blocks are contiguous: the source pointer
   // simply advances by WAVES pieces per DMA for the whole kernel (the stream ends with one block of padding, so the
   // last iteration's prefetch reads defined bytes that are never consumed)
-  const unsigned char* wp = p.wpk + (long long)wave * PIECE;
+  const unsigned char* wp = p.wpk + blockIdx.y * p.sW + (long long)wave * PIECE;
   const unsigned voff = lane * 16;
   const unsigned wbase = wave * PIECE;
   auto dma = [&](int stage, int q) {
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   float* const outb = p.out + blockIdx.y * p.sOut;
   float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<C, ACT == 3>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
+  load_x_frags<C, (ACT >= 3)>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
 
   f32x16 oacc[NT];
 #pragma unroll
@@ -443,6 +443,25 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
           for (int i = 0; i < 16; ++i) hacc[i] *= inv;
         }
+        if (ACT == 4 && j == 0) {
+          // 8 keys per head, four heads per chunk: head g of the chunk = rows 8g..8g+7 = registers 4g..4g+3 of this lane
+          // (rows 8g + 4hf + 0..3) and of lane ^ 32
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float mx = fmaxf(fmaxf(hacc[4 * g], hacc[4 * g + 1]), fmaxf(hacc[4 * g + 2], hacc[4 * g + 3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              hacc[4 * g + i] = __expf(hacc[4 * g + i] - mx);
+              sum += hacc[4 * g + i];
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hacc[4 * g + i] *= inv;
+          }
+        }
         // activation + hi/lo split of value pairs [8j/(2NT), 8(j+1)/(2NT)) of this chunk, spread over the 2NT steps
 #pragma unroll
         for (int q = (8 * j) / (2 * NT); q < (8 * (j + 1)) / (2 * NT); ++q) {
@@ -524,6 +543,10 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
                                                        const long long units, const int single) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= units) return;
+  W1 += (long long)blockIdx.y * Hd * C;  // batch entries: contiguous [Hd,C], [Hd], [C,Hd] blocks, contiguous streams
+  if (b1) b1 += (long long)blockIdx.y * Hd;
+  W2 += (long long)blockIdx.y * C * Hd;
+  out += (long long)blockIdx.y * units * 16;
   const int KS = C / 16, NT = C / 32, NC = Hd / 32;
   const int lane = (int)(u & 63);
   const long long pg = u >> 6;
@@ -830,11 +853,18 @@ void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
 __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                             const float* __restrict__ wqT, const float* __restrict__ wo,
                                                             float* __restrict__ W1, float* __restrict__ b1,
-                                                            float* __restrict__ W2, const int L) {
+                                                            float* __restrict__ W2, const int L, const int G) {
+  // G = key slots per head (32 or 8), hidden = 8 * G; blockIdx.y = batch entry (its own keys / values and outputs)
   constexpr int C = 256, HD = 32;
+  const int Hd = 8 * G;
+  k += (long long)blockIdx.y * L * C;
+  v += (long long)blockIdx.y * L * C;
+  W1 += (long long)blockIdx.y * Hd * C;
+  b1 += (long long)blockIdx.y * Hd;
+  W2 += (long long)blockIdx.y * C * Hd;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < C * C) {  // W1[h*32 + j][i] = sum_c k[j][h*32 + c] * wqT[i][h*32 + c]
-    const int r = idx / C, i = idx - r * C, h = r / HD, j = r - h * HD;
+  if (idx < Hd * C) {  // W1[h*G + j][i] = sum_c k[j][h*32 + c] * wqT[i][h*32 + c]
+    const int r = idx / C, i = idx - r * C, h = r / G, j = r - h * G;
     float a = 0.f;
     if (j < L) {
       const f32x4* kp = reinterpret_cast<const f32x4*>(k + j * C + h * HD);
@@ -846,8 +876,8 @@ __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restr
       }
     }
     W1[idx] = a;
-  } else if (idx < 2 * C * C) {  // W2[n][h*32 + j] = sum_c wo[n][h*32 + c] * v[j][h*32 + c]
-    const int e = idx - C * C, n = e / C, r = e - n * C, h = r / HD, j = r - h * HD;
+  } else if (idx < 2 * Hd * C) {  // W2[n][h*G + j] = sum_c wo[n][h*32 + c] * v[j][h*32 + c]
+    const int e = idx - Hd * C, n = e / Hd, r = e - n * Hd, h = r / G, j = r - h * G;
     float a = 0.f;
     if (j < L) {
       const f32x4* vp = reinterpret_cast<const f32x4*>(v + j * C + h * HD);
@@ -859,8 +889,8 @@ __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restr
       }
     }
     W2[e] = a;
-  } else if (idx < 2 * C * C + C) {  // b1[h*32 + j] = sum_c k[j][h*32 + c] * wqT[256][h*32 + c]; padded keys: -inf
-    const int r = idx - 2 * C * C, h = r / HD, j = r - h * HD;
+  } else if (idx < 2 * Hd * C + Hd) {  // b1[h*G + j] = sum_c k[j][h*32 + c] * wqT[256][h*32 + c]; padded keys: -inf
+    const int r = idx - 2 * Hd * C, h = r / G, j = r - h * G;
     float a = -1.0e30f;
     if (j < L) {
       a = 0.f;
@@ -887,6 +917,17 @@ extern "C" int tce_ffn_pack_f32(const float* W1, const float* b1, const float* W
   hipLaunchKernelGGL(ffn_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W1, b1, W2,
                      (unsigned char*)packed, C, Hd, ffn_pieces(C), units, tce_gemm_single_pass());
   TCE_CHECK_LAUNCH("tce_ffn_pack_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_ffn_pack_batched_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
+                                        int32_t batch, tceStream stream) {
+  TCE_CHECK_ARG(ffn_shape_ok(C, Hd) && batch > 0, "tce_ffn_pack_batched_f32: unsupported shape C=%d hidden=%d batch=%d", C, Hd, batch);
+  TCE_CHECK_ARG(W1 && W2 && packed && tce_aligned16(packed), "tce_ffn_pack_batched_f32: null / misaligned pointer");
+  const long long units = ffn_units(C, Hd);
+  hipLaunchKernelGGL(ffn_pack_kernel, dim3(tce_cdiv(units, 256), batch), dim3(256), 0, (hipStream_t)stream, W1, b1, W2,
+                     (unsigned char*)packed, C, Hd, ffn_pieces(C), units, tce_gemm_single_pass());
+  TCE_CHECK_LAUNCH("tce_ffn_pack_batched_f32");
   return TCE_OK;
 }
 
@@ -917,13 +958,15 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
 }
 
 extern "C" int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
-                                     float* W2, int32_t L, tceStream stream) {
+                                     float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream) {
   TCE_CHECK_ARG(k && v && wqT_ext && wo && W1 && b1 && W2, "tce_xattn_prepare_f32: null pointer");
-  TCE_CHECK_ARG(L >= 1 && L <= 32, "tce_xattn_prepare_f32: 1 <= L <= 32 keys (got %d)", L);
+  TCE_CHECK_ARG((group == 32 || group == 8) && L >= 1 && L <= group && batch >= 1,
+                "tce_xattn_prepare_f32: group must be 32 or 8 and 1 <= L <= group (L=%d group=%d)", L, group);
   TCE_CHECK_ARG(tce_aligned16(k) && tce_aligned16(v) && tce_aligned16(wqT_ext) && tce_aligned16(wo),
                 "tce_xattn_prepare_f32: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(xattn_prepare_kernel, dim3(tce_cdiv(2 * 256 * 256 + 256, 256)), dim3(256), 0, (hipStream_t)stream, k, v,
-                     wqT_ext, wo, W1, b1, W2, L);
+  const int Hd = 8 * group;
+  hipLaunchKernelGGL(xattn_prepare_kernel, dim3(tce_cdiv(2 * Hd * 256 + Hd, 256), batch), dim3(256), 0, (hipStream_t)stream,
+                     k, v, wqT_ext, wo, W1, b1, W2, L, group);
   TCE_CHECK_LAUNCH("tce_xattn_prepare_f32");
   return TCE_OK;
 }
@@ -933,6 +976,7 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   const tceXattnArgs& q = *args;
   TCE_CHECK_ARG(q.M > 0 && q.x && q.packed && q.bo && q.out, "tce_xattn_fused_f32: null pointer or M <= 0");
   TCE_CHECK_ARG(q.res_mode == 1 || q.res_mode == 2, "tce_xattn_fused_f32: res_mode must be 1 (add) or 2 (multiply)");
+  TCE_CHECK_ARG(q.group == 32 || q.group == 8, "tce_xattn_fused_f32: group (key slots per head) must be 32 or 8");
   TCE_CHECK_ARG(q.ldx >= 256 && q.ldo >= 256 && q.ldx % 4 == 0 && q.ldo % 4 == 0 && (!q.res || (q.ldres >= 256 && q.ldres % 4 == 0)) &&
                     (!q.a2 || (q.lda2 >= 256 && q.lda2 % 4 == 0)) && q.sX % 4 == 0 && q.sRes % 4 == 0 && q.sOut % 4 == 0,
                 "tce_xattn_fused_f32: bad row pitch / batch stride");
@@ -944,11 +988,12 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   FfnArgs a = {};
   a.x = q.x; a.wpk = (const unsigned char*)q.packed; a.b2 = q.bo; a.g_out = q.g_out; a.be_out = q.be_out; a.out = q.out;
   a.ldx = q.ldx; a.ldo = q.ldo; a.a2 = q.a2; a.lda2 = q.lda2; a.a2_rows = q.a2_rows; a.res = q.res; a.ldres = q.ldres;
-  a.res_mode = q.res_mode; a.sX = q.sX; a.sRes = q.sRes; a.sOut = q.sOut;
-  a.M = q.M; a.NI = 256 / 32 + 1; a.eps_out = q.eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  a.res_mode = q.res_mode; a.sX = q.sX; a.sRes = q.sRes; a.sOut = q.sOut; a.sW = q.sW;
+  a.M = q.M; a.NI = (8 * q.group) / 32 + 1; a.eps_out = q.eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
   const int batch = q.batch > 0 ? q.batch : 1;
   const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
-  hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3>), grid, block, 0, (hipStream_t)stream, a);
+  if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4>), grid, block, 0, (hipStream_t)stream, a);
   TCE_CHECK_LAUNCH("tce_xattn_fused_f32");
   return TCE_OK;
 }

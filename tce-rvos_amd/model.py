@@ -239,7 +239,8 @@ class ReferFormer(nn.Module):
                     w[pre + "q.w"], w[pre + "k.w"], w[pre + "v.w"] = W[:d], W[d:2 * d], W[2 * d:]
                     w[pre + "q.b"], w[pre + "k.b"], w[pre + "v.b"] = B[:d], B[d:2 * d], B[2 * d:]
                     w[pre + "qk.w"], w[pre + "qk.b"] = W[:2 * d], B[:2 * d]
-                    if pre.endswith("multihead_attn.") and d == 256:  # text cross-attention sites: static half of the fold
+                    if (pre.endswith("multihead_attn.") or pre.endswith("frame_token_atten.")) and d == 256:
+                        # short-key cross-attention sites (text keys; frame tokens): static half of the fold
                         w[pre + "q.wT:x"] = ops.xattn_static(W[:d], B[:d])
                 if v_is_conv(sd[k]) and sd[k].shape[-1] == 3:
                     w[k + ":cl"] = sd[k].detach().permute(0, 2, 3, 1).reshape(sd[k].shape[0], -1).contiguous()

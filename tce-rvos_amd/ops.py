@@ -664,24 +664,29 @@ def xattn_static(wq, bq, scale=32 ** -0.5):
     return (torch.cat([wq.t(), bq[None]], 0) * scale).contiguous()
 
 
-def xattn_pack(k, v, wqT_ext, wo, L, alloc):
-    """Per clip: folds the projected keys / values [L,256] of the 8 heads into W1, b1, W2 and packs the weight stream."""
+def xattn_pack(k, v, wqT_ext, wo, L, alloc, group=32, batch=1):
+    """Per clip: folds the projected keys / values ([batch][L,256]) of the 8 heads into W1, b1, W2 and packs the weight
+    stream(s).  Returns a uint8 tensor [batch, bytes_per_stream]."""
     _chk(k, "k")
     _chk(v, "v")
-    W1, b1, W2 = alloc(256, 256), alloc(256), alloc(256, 256)
+    Hd = 8 * group
+    W1, b1, W2 = alloc(batch, Hd, 256), alloc(batch, Hd), alloc(batch, 256, Hd)
     check(lib().tce_xattn_prepare_f32(k.data_ptr(), v.data_ptr(), wqT_ext.data_ptr(), wo.data_ptr(), W1.data_ptr(), b1.data_ptr(),
-                                      W2.data_ptr(), L, _stream()), "tce_xattn_prepare_f32")
-    nbytes = lib().tce_ffn_packed_bytes(256, 256)
-    pk = alloc(nbytes, dtype=torch.uint8)
-    return ffn_pack(W1, b1, W2, out=pk)
+                                      W2.data_ptr(), L, group, batch, _stream()), "tce_xattn_prepare_f32")
+    nbytes = lib().tce_ffn_packed_bytes(256, Hd)
+    pk = alloc(batch, nbytes, dtype=torch.uint8)
+    check(lib().tce_ffn_pack_batched_f32(W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), pk.data_ptr(), 256, Hd, batch, _stream()),
+          "tce_ffn_pack_batched_f32")
+    return pk
 
 
 def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_mode=RES_ADD, ln_out=None, eps_out=1e-5,
-                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256):
+                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256, group=32, per_batch_weights=False):
     from ._lib import XattnArgs
     q = XattnArgs()
     q.x, q.packed, q.bo, q.out = x.data_ptr(), pk.data_ptr(), bo.data_ptr(), out.data_ptr()
-    q.M, q.batch, q.res_mode, q.eps_out = M, batch, res_mode, eps_out
+    q.M, q.batch, q.res_mode, q.eps_out, q.group = M, batch, res_mode, eps_out, group
+    q.sW = pk.stride(0) if (per_batch_weights and pk.dim() == 2) else 0
     q.ldx, q.ldo, q.ldres, q.lda2 = ldx, ldo, ldres, lda2
     q.sX, q.sRes, q.sOut = sX, sRes, sOut
     if a2 is not None:
@@ -700,5 +705,5 @@ def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_m
     e0.record()
     go()
     e1.record()
-    GEMM_PROFILE.append(("xattn(ffn_fused_kernel<256,4,3>", False, 4.0 * M * 256 * 256 * batch, e0, e1))
+    GEMM_PROFILE.append(("xattn(ffn_fused_kernel<256,4,3|4>", False, 4.0 * M * 256 * 8 * group * batch, e0, e1))
     return out

@@ -242,17 +242,25 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             ln_(token, fp + "norm2")
             # (3) every pixel attends to the F tokens of its own frame (:480-484)
             pre = fp + "frame_token_atten."
-            q = A(T * S, D)
-            gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
-                    sA=S * D, sA2=0, sC=S * D)
             k = A(T * Fk, D)
             gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
                     sA=Fk * D, sA2=0, sC=Fk * D)
             v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            att = A(T * S, D)
-            ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
-            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
-                         w[fp + "norm3.bias"])
+            if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
+                # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
+                # launch (the keys / values differ per frame: one folded weight stream per frame)
+                pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], Fk, A, group=8, batch=T)
+                ops.xattn_fused(src, pk, w[pre + "out_proj.bias"], S, src, a2=lvl_pos,
+                                ln_out=(w[fp + "norm3.weight"], w[fp + "norm3.bias"]), batch=T, sX=S * D, sOut=S * D,
+                                group=8, per_batch_weights=True)
+            else:
+                q = A(T * S, D)
+                gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
+                        sA=S * D, sA2=0, sC=S * D)
+                att = A(T * S, D)
+                ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
+                _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
+                             w[fp + "norm3.bias"])
             ar.release(m0)
             # (4) FFN over all pixels (:489-491)
             ffn(src, T * S, fp, norm=fp + "norm4")

@@ -757,3 +757,32 @@ def test_xattn_fused(ops, M, L, mode):
         out = wide[:, :mb].reshape(M, Cn)
         assert float(wide[:, mb:].abs().max()) == 0.0
     close(out, ref, 3e-4, 3e-4)
+
+
+def test_xattn_fused_eight_key_groups_per_frame(ops):
+    """FrameTokenLayer's pixel <- token attention (tce_deformable_transformer.py:480-484): every frame has its own 8 keys /
+    values, so the folded weights differ per batch entry; softmax over groups of 8 inside a 32-unit chunk."""
+    g = torch.Generator().manual_seed(99)
+    T, S, F_, Cn = 3, 1500, 8, 256
+    x = torch.randn(T, S, Cn, generator=g)
+    pos = torch.randn(S, Cn, generator=g) * 0.5
+    tok = torch.randn(T, F_, Cn, generator=g)
+    mha = torch.nn.MultiheadAttention(Cn, 8)
+    with torch.no_grad():
+        for p_ in mha.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.06 if p_.dim() == 2 else 0.2))
+    Wq, Wk, Wv = mha.in_proj_weight.detach().chunk(3, 0)
+    bq, bk, bv = mha.in_proj_bias.detach().chunk(3, 0)
+    gam, bet = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    with torch.no_grad():   # seq-first: (L = S, N = T) queries against (F, T) keys
+        att = mha((x + pos).permute(1, 0, 2), tok.permute(1, 0, 2), tok.permute(1, 0, 2))[0].permute(1, 0, 2)
+    ref = F.layer_norm(x + att, (Cn,), gam, bet, 1e-5)
+    k = F.linear(tok, Wk, bk).reshape(T * F_, Cn)
+    v = F.linear(tok, Wv, bv).reshape(T * F_, Cn)
+    ar = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device="cuda")
+    pk = ops.xattn_pack(dev(k), dev(v), ops.xattn_static(dev(Wq), dev(bq)), dev(mha.out_proj.weight.detach()), F_, ar,
+                        group=8, batch=T)
+    xd = dev(x.reshape(T * S, Cn))
+    ops.xattn_fused(xd, pk, dev(mha.out_proj.bias.detach()), S, xd, a2=dev(pos), ln_out=(dev(gam), dev(bet)), batch=T,
+                    sX=S * Cn, sOut=S * Cn, group=8, per_batch_weights=True)
+    close(xd.view(T, S, Cn), ref, 3e-4, 3e-4)
