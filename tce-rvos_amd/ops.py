@@ -498,11 +498,12 @@ def rowlin_lookup(w, N, K, ldw=None):
     return ROWLIN_TABLE.get((w.data_ptr(), N, K, K if ldw is None else ldw)) if get_gemm_mode() != "f32" else None
 
 
-# Opt-in (TCE_SPLITK=1).  Measured at config 2: the skinny GEMMs live in the graph's side branches (text encoder
-# beside the backbone, decoder beside the pixel decoder) and are already hidden; splitting them only adds workgroups that
-# compete with the main branch (85.3 vs 86.1 clips/s on the same box).  Stand-alone the 32x768x3072 projection drops
-# from 43 us to ~12 us, which matters when the text encoder runs alone.
-SPLITK_ENABLED = os.environ.get("TCE_SPLITK", "0") == "1"
+# Split-K for the skinny, deep GEMMs of the side branches (RoBERTa at 32 tokens, the decoder on 25 rows); TCE_SPLITK=0
+# disables.  Round 1 measured no gain (the branches were hidden behind a slower main chain); with the round-2 main
+# chain (fused FFN / cross-attention launches) the text branch sits on the critical path and split-K is worth 2.7 %
+# of the clip (9.24 -> 8.99 ms on one box, A/B in one gpurun call).  Stand-alone the 32x768x3072 projection drops from
+# 43 us to ~12 us.
+SPLITK_ENABLED = os.environ.get("TCE_SPLITK", "1") == "1"
 
 
 def splitk_for(M, N, K):
