@@ -487,15 +487,21 @@ class ReferFormer(nn.Module):
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
             return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot))
-        arena, side_arena, side_stream = res
-        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False)
+        arena, side_arena, side_stream, arena2, stream2 = res
+        import os
+        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False,
+                        fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None)
 
     def _capture(self, key, statics, fn, like):
         """Captures fn((arena, side_arena, side_stream)) into a graph; the arenas belong to the graph (their
         addresses are baked into it)."""
         T, _, H0, W0 = like.shape
+        tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
         res = (ops.Arena(like.device, self._arena_bytes(T, H0, W0)),
                ops.Arena(like.device, T * self._tokens_per_frame(H0, W0) * 256 * 4 * 4 + (32 << 20)),
+               torch.cuda.Stream(device=like.device),
+               # third branch: the pixel decoder's stride-4 lateral path (tgt + its self-attention / FFN temporaries)
+               ops.Arena(like.device, int(tok0 * 4 * (2048 * 1.1 + 256 * 4)) + (64 << 20)),
                torch.cuda.Stream(device=like.device))
         fn(None if False else res)  # eager warm-up on the same resources: builds per-shape constants, lazy inits
         torch.cuda.synchronize()
@@ -503,7 +509,7 @@ class ReferFormer(nn.Module):
         with torch.cuda.graph(graph):
             out = fn(res)
         _ALL_GRAPHS.append(graph)  # executables outlive their cache entry (see _ALL_GRAPHS)
-        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel())
+        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel() + res[3].buf.numel())
         self._graphs[key] = ent
         # LRU bound (entries and bytes); the entry just captured always stays.  Eviction returns the arenas.
         while len(self._graphs) > 1 and (len(self._graphs) > self.max_graphs or

@@ -73,13 +73,14 @@ class _Fork:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
-def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True):
+def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
     beside the pixel decoder's large kernels; it needs its own arena because both branches allocate.
     clone_outputs=False returns views into the arenas (valid until the arenas are used again): the graph path owns its
-    arenas and copies the outputs out once per replay, so a second copy inside the graph would be wasted."""
+    arenas and copies the outputs out once per replay, so a second copy inside the graph would be wasted.
+    fork2 = (arena, stream): a third concurrent branch for the pixel decoder's stride-4 lateral path (see there)."""
     cfg, w = model.cfg, model._packed
     dev = frames.device
     T, _, H0, W0 = frames.shape
@@ -134,10 +135,19 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
     src = A(T * S, D)  # [T, S, 256]: the encoder sequence
     chs = cfg.num_channels
-    for l in range(4):
+    # The four levels are independent (they write disjoint slices of src): level 0 stays on the main stream, level 1 and
+    # levels 2+3 run as parallel graph branches on the two side streams, which are idle here (the text branch has
+    # joined, the decoder / lateral branches have not started).  No buffer is released before every branch has joined, so
+    # concurrent levels never share memory.
+    m_levels = ar.mark()
+    stream2 = fork2[1] if fork2 is not None else None
+    lvl_forks = []
+    for l, lvl_stream in ((1, side_stream), (2, stream2), (3, stream2), (0, None)):
         h, ww = lvl_sizes[l]
         hw = h * ww
-        m0 = ar.mark()
+        fk_ = _Fork(lvl_stream)
+        lvl_forks.append(fk_)
+        fk_.__enter__()
         if l < 3:
             s = _lin(A, feats[1 + l], T * hw, chs[1 + l], w[f"input_proj.{l}.0.weight"], w[f"input_proj.{l}.0.bias"], D)
         else:
@@ -154,16 +164,18 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]
             ops.xattn_fused(s, fpk, w["fusion_module.multihead_attn.out_proj.bias"], hw, src[starts[l]:], res_mode=RES_MUL,
                             batch=T, sX=hw * D, sRes=hw * D, sOut=S * D)
-            ar.release(m0)
-            continue
-        q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
-        att = A(T * hw, D)
-        ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-        # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
-        gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
-                bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
-                sA=hw * D, sC=S * D, sRes=hw * D)
-        ar.release(m0)
+        else:
+            q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
+            att = A(T * hw, D)
+            ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
+            gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
+                    bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
+                    sA=hw * D, sC=S * D, sRes=hw * D)
+        fk_.__exit__(None, None, None)
+    for fk_ in lvl_forks:
+        fk_.join()
+    ar.release(m_levels)
 
     _stage("input_proj + fusion")
     # ------------------------------------------------------------------ encoder (:611-627)
@@ -342,7 +354,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
-    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, fork2=fork2)
     dec_fork.join()
 
     _stage("pixel decoder")
@@ -498,21 +510,25 @@ def _resnet_backbone(model, frames, ar, sizes):
     return feats
 
 
-def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_):
-    """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level."""
+def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, fork2=None):
+    """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level.
+
+    The lateral branch of a level (1x1 adapter + GroupNorm + VisionLanguageBlock) depends only on the encoder memory /
+    the backbone map and the text; only the top-down merge + 3x3 convolution chain is sequential (stage 4 -> 1).  With
+    `fork2 = (arena, stream)` the stride-4 lateral branch -- about as much work as the three coarser stages together --
+    runs as a parallel graph branch from the start, so the coarser stages' small, latency-bound launches execute in
+    the tails of its big kernels."""
     cfg, w = model.cfg, model._packed
     A = ar.alloc
     sizes, S, starts = sc["sizes"], sc["S"], sc["starts"]
     pd = "pixel_decoder."
-    y = None
-    y_hw = None
-    out_final = None
-    for stage in (4, 3, 2, 1):
+
+    def lateral(stage, arx):
+        """tgt [T*hw, 256] of `stage`, allocated in `arx` (temporaries released, tgt stays)."""
+        A = arx.alloc
         h, ww = sizes[stage - 1]
         hw = h * ww
         pos = sc["pos"][stage - 1]  # [hw, 256] backbone-level sine map (no level embedding)
-        y_new = A(T * hw, D)
-        m0 = ar.mark()
         # lateral 1x1 conv (no bias) + GN(8)
         vis = A(T * hw, D)
         if stage > 1:
@@ -522,55 +538,79 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_):
         else:
             c0 = cfg.num_channels[0]
             gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
+        m1 = arx.mark()
         tgt = ops.groupnorm_cl(vis, w[f"{pd}adapter_{stage}.norm.weight"], w[f"{pd}adapter_{stage}.norm.bias"], T, hw, D, 8,
                                out=vis, alloc=A)
-        if cfg.vlblock:
-            bp = f"{pd}cross_attn_{stage}."
-            pre = bp + "self_attn."
-            red = sc["red"].get(stage)
-            m1 = ar.mark()
-            if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
-                nh_, nw_, pos_low = red
-                n_low = T * nh_ * nw_
-                x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
-                qk = A(n_low, 2 * D)
-                gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
-                        lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
-                v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
-                att = A(n_low, D)
-                ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-                o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
-                ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
-            else:
-                n = T * hw
-                qk = A(n, 2 * D)
-                gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
-                        batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
-                v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
-                att = A(n, D)
-                ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-                gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                        ldres=D, res_mode=RES_ADD)
-            ar.release(m1)
-            ln_(tgt, bp + "norm1")
-            # text cross-attention (:366-371)
-            pre = bp + "multihead_attn."
-            m1 = ar.mark()
-            tk, tv, pk = vl_sites[stage]
-            if pk is not None:
-                # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
-                ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
-                                ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
-            else:
-                q = A(T * hw, D)
-                gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
-                        sA2=0, sC=hw * D)
-                att = A(T * hw, D)
-                ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-                _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
-                             w[bp + "norm2.bias"])
-            ar.release(m1)
-            ffn(tgt, T * hw, bp, norm=bp + "norm3")
+        arx.release(m1)
+        if not cfg.vlblock:
+            return tgt
+        bp = f"{pd}cross_attn_{stage}."
+        pre = bp + "self_attn."
+        red = sc["red"].get(stage)
+        m1 = arx.mark()
+        if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
+            nh_, nw_, pos_low = red
+            n_low = T * nh_ * nw_
+            x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
+            qk = A(n_low, 2 * D)
+            gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
+                    lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
+            v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(n_low, D)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+            o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
+            ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
+        else:
+            n = T * hw
+            qk = A(n, 2 * D)
+            gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
+                    batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
+            v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(n, D)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+            gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                    ldres=D, res_mode=RES_ADD)
+        arx.release(m1)
+        ln_(tgt, bp + "norm1")
+        # text cross-attention (:366-371)
+        pre = bp + "multihead_attn."
+        m1 = arx.mark()
+        tk, tv, pk = vl_sites[stage]
+        if pk is not None:
+            # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
+            ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
+                            ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
+        else:
+            q = A(T * hw, D)
+            gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
+                    sA2=0, sC=hw * D)
+            att = A(T * hw, D)
+            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
+                         w[bp + "norm2.bias"])
+        arx.release(m1)
+        ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx)
+        return tgt
+
+    # the stride-4 lateral branch: beside the coarser stages when a second fork is available, first otherwise
+    ar2, stream2 = fork2 if fork2 is not None else (None, None)
+    if ar2 is not None:
+        ar2.reset()
+    lat_fork = _Fork(stream2)
+    with lat_fork:
+        tgt1 = lateral(1, ar2 if ar2 is not None else ar)
+    y = None
+    y_hw = None
+    for stage in (4, 3, 2, 1):
+        h, ww = sizes[stage - 1]
+        hw = h * ww
+        y_new = A(T * hw, D)
+        m0 = ar.mark()
+        if stage == 1:
+            lat_fork.join()
+            tgt = tgt1
+        else:
+            tgt = lateral(stage, ar)
         # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
         if y is not None:
             ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
