@@ -348,9 +348,23 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         ops.box_refine(t3, refs2, out=inter_ref)
         return hs, inter_ref, refs2, 2, logits
 
+    npar = cfg.num_gen_params
     dec_fork = _Fork(side_stream if side_arena is not None else None)
     with dec_fork:
         hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
+        # controller MLP + parameter packing of the dynamic mask head (:371-373, 536-559): depend on hs only, so they
+        # ride in the decoder branch instead of the main chain's tail
+        dA = dar.alloc
+        c1 = dA(nl * T * Q, D)
+        gemm_ex(hs, w["controller.layers.0.weight"], c1, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.0.bias"],
+                act=ACT_RELU)
+        c2 = dA(nl * T * Q, D)
+        gemm_ex(c1, w["controller.layers.1.weight"], c2, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.1.bias"],
+                act=ACT_RELU)
+        params = _lin(dA, c2, nl * T * Q, D, w["controller.layers.2.weight"], w["controller.layers.2.bias"], npar)
+        w0f = dA(T, nl * Q * 8, cfg.mask_dim)
+        tail = dA(nl, T * Q, 112)
+        ops.mask_pack(params, nl, T, Q, cfg.mask_dim, w0f, tail)
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
@@ -360,18 +374,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     _stage("pixel decoder")
     # ------------------------------------------------------------------ dynamic mask head (:371-380, 426-510)
     h4, w4 = sizes[0]
-    npar = cfg.num_gen_params
     m0 = ar.mark()
-    c1 = A(nl * T * Q, D)
-    gemm_ex(hs, w["controller.layers.0.weight"], c1, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.0.bias"],
-            act=ACT_RELU)
-    c2 = A(nl * T * Q, D)
-    gemm_ex(c1, w["controller.layers.1.weight"], c2, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.1.bias"],
-            act=ACT_RELU)
-    params = _lin(A, c2, nl * T * Q, D, w["controller.layers.2.weight"], w["controller.layers.2.bias"], npar)
-    w0f = A(T, nl * Q * 8, cfg.mask_dim)
-    tail = A(nl, T * Q, 112)
-    ops.mask_pack(params, nl, T, Q, cfg.mask_dim, w0f, tail)
     G = A(T, h4 * w4, nl * Q * 8)
     ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
     masks = A(nl, T, Q, h4, w4)
