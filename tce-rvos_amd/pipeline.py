@@ -132,17 +132,53 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     _stage("backbone")
     text_fork.join()
     _stage("text join")
+
+    def ln_(x, pre):
+        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
+
+    fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
+
+    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
+        """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
+        (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
+        pk = w.get(pre + "ffn:pk") if fused_ok else None
+        if pk is not None and M >= FFN_FUSED_MIN_ROWS:
+            ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
+                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
+            return
+        A = ar.alloc
+        m1 = ar.mark()
+        hdn = A(M, ff)
+        gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
+        sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
+        gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
+                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
+        ar.release(m1)
+        if norm:
+            ln_(x, norm)
+
+    # ------------------------------------------------------------------ pixel decoder, stride-4 lateral branch, EARLY
+    # adapter_1 + GroupNorm + VisionLanguageBlock at stride 4 read the backbone's C2 map and the text only -- not the
+    # encoder memory (segmentation.py:187-196 with the backbone feature as the last lateral input) -- so this millisecond
+    # of work starts here, as a parallel graph branch beside input_proj and the whole encoder (whose frame-token chains
+    # and MSDA gathers leave the matrix cores idle), and is joined when the top-down chain reaches stride 4.
+    ar2, stream2 = fork2 if fork2 is not None else (None, None)
+    lat1 = None
+    if ar2 is not None and stream2 is not None:
+        ar2.reset()
+        lat1_fork = _Fork(stream2)
+        with lat1_fork:
+            lat1 = (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2))
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
     src = A(T * S, D)  # [T, S, 256]: the encoder sequence
     chs = cfg.num_channels
-    # The four levels are independent (they write disjoint slices of src): level 0 stays on the main stream, level 1 and
-    # levels 2+3 run as parallel graph branches on the two side streams, which are idle here (the text branch has
-    # joined, the decoder / lateral branches have not started).  No buffer is released before every branch has joined, so
-    # concurrent levels never share memory.
+    # The four levels are independent (they write disjoint slices of src): level 0 stays on the main stream, levels 1-3
+    # run as a parallel graph branch on the side stream, which is idle here (the text branch has joined, the decoder
+    # branch has not started).  No buffer is released before the branch has joined, so concurrent levels never share
+    # memory.
     m_levels = ar.mark()
-    stream2 = fork2[1] if fork2 is not None else None
     lvl_forks = []
-    for l, lvl_stream in ((1, side_stream), (2, stream2), (3, stream2), (0, None)):
+    for l, lvl_stream in ((1, side_stream), (2, side_stream), (3, side_stream), (0, None)):
         h, ww = lvl_sizes[l]
         hw = h * ww
         fk_ = _Fork(lvl_stream)
@@ -184,30 +220,6 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     if Fk > 0:
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
-
-    def ln_(x, pre):
-        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
-
-    fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
-
-    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
-        """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
-        (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
-        pk = w.get(pre + "ffn:pk") if fused_ok else None
-        if pk is not None and M >= FFN_FUSED_MIN_ROWS:
-            ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
-                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
-            return
-        A = ar.alloc
-        m1 = ar.mark()
-        hdn = A(M, ff)
-        gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
-        sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
-        gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
-                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
-        ar.release(m1)
-        if norm:
-            ln_(x, norm)
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
              ar=ar, norm=None):
@@ -368,7 +380,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
-    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, fork2=fork2)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1)
     dec_fork.join()
 
     _stage("pixel decoder")
@@ -513,95 +525,92 @@ def _resnet_backbone(model, frames, ar, sizes):
     return feats
 
 
-def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, fork2=None):
-    """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level.
-
-    The lateral branch of a level (1x1 adapter + GroupNorm + VisionLanguageBlock) depends only on the encoder memory /
-    the backbone map and the text; only the top-down merge + 3x3 convolution chain is sequential (stage 4 -> 1).  With
-    `fork2 = (arena, stream)` the stride-4 lateral branch -- about as much work as the three coarser stages together --
-    runs as a parallel graph branch from the start, so the coarser stages' small, latency-bound launches execute in
-    the tails of its big kernels."""
+def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
+    """Lateral branch of one FPN level (segmentation.py:187-196,326-377): 1x1 adapter + GroupNorm(8) + VisionLanguageBlock.
+    Returns tgt [T*hw, 256] allocated in `arx` (temporaries released, tgt stays).  Stage 1 reads the backbone map
+    (memory may be None), stages 2-4 the encoder memory."""
     cfg, w = model.cfg, model._packed
-    A = ar.alloc
     sizes, S, starts = sc["sizes"], sc["S"], sc["starts"]
     pd = "pixel_decoder."
-
-    def lateral(stage, arx):
-        """tgt [T*hw, 256] of `stage`, allocated in `arx` (temporaries released, tgt stays)."""
-        A = arx.alloc
-        h, ww = sizes[stage - 1]
-        hw = h * ww
-        pos = sc["pos"][stage - 1]  # [hw, 256] backbone-level sine map (no level embedding)
-        # lateral 1x1 conv (no bias) + GN(8)
-        vis = A(T * hw, D)
-        if stage > 1:
-            l = stage - 2  # encoder level index: stage 4 <-> level 2 (32x)
-            gemm_ex(memory[starts[l]:], w[f"{pd}adapter_{stage}.weight"], vis, hw, D, D, D, D, D, batch=T, sA=S * D,
-                    sC=hw * D)
-        else:
-            c0 = cfg.num_channels[0]
-            gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
-        m1 = arx.mark()
-        tgt = ops.groupnorm_cl(vis, w[f"{pd}adapter_{stage}.norm.weight"], w[f"{pd}adapter_{stage}.norm.bias"], T, hw, D, 8,
-                               out=vis, alloc=A)
-        arx.release(m1)
-        if not cfg.vlblock:
-            return tgt
-        bp = f"{pd}cross_attn_{stage}."
-        pre = bp + "self_attn."
-        red = sc["red"].get(stage)
-        m1 = arx.mark()
-        if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
-            nh_, nw_, pos_low = red
-            n_low = T * nh_ * nw_
-            x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
-            qk = A(n_low, 2 * D)
-            gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
-                    lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
-            v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            att = A(n_low, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-            o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
-            ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
-        else:
-            n = T * hw
-            qk = A(n, 2 * D)
-            gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
-                    batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
-            v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            att = A(n, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-            gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                    ldres=D, res_mode=RES_ADD)
-        arx.release(m1)
-        ln_(tgt, bp + "norm1")
-        # text cross-attention (:366-371)
-        pre = bp + "multihead_attn."
-        m1 = arx.mark()
-        tk, tv, pk = vl_sites[stage]
-        if pk is not None:
-            # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
-            ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
-                            ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
-        else:
-            q = A(T * hw, D)
-            gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
-                    sA2=0, sC=hw * D)
-            att = A(T * hw, D)
-            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
-                         w[bp + "norm2.bias"])
-        arx.release(m1)
-        ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx)
+    A = arx.alloc
+    h, ww = sizes[stage - 1]
+    hw = h * ww
+    pos = sc["pos"][stage - 1]  # [hw, 256] backbone-level sine map (no level embedding)
+    # lateral 1x1 conv (no bias) + GN(8)
+    vis = A(T * hw, D)
+    if stage > 1:
+        l = stage - 2  # encoder level index: stage 4 <-> level 2 (32x)
+        gemm_ex(memory[starts[l]:], w[f"{pd}adapter_{stage}.weight"], vis, hw, D, D, D, D, D, batch=T, sA=S * D,
+                sC=hw * D)
+    else:
+        c0 = cfg.num_channels[0]
+        gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
+    m1 = arx.mark()
+    tgt = ops.groupnorm_cl(vis, w[f"{pd}adapter_{stage}.norm.weight"], w[f"{pd}adapter_{stage}.norm.bias"], T, hw, D, 8,
+                           out=vis, alloc=A)
+    arx.release(m1)
+    if not cfg.vlblock:
         return tgt
+    bp = f"{pd}cross_attn_{stage}."
+    pre = bp + "self_attn."
+    red = sc["red"].get(stage)
+    m1 = arx.mark()
+    if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
+        nh_, nw_, pos_low = red
+        n_low = T * nh_ * nw_
+        x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
+        qk = A(n_low, 2 * D)
+        gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
+                lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
+        v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
+        att = A(n_low, D)
+        ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+        o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
+        ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
+    else:
+        n = T * hw
+        qk = A(n, 2 * D)
+        gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
+                batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
+        v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
+        att = A(n, D)
+        ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+        gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                ldres=D, res_mode=RES_ADD)
+    arx.release(m1)
+    ln_(tgt, bp + "norm1")
+    # text cross-attention (:366-371)
+    pre = bp + "multihead_attn."
+    m1 = arx.mark()
+    tk, tv, pk = vl_sites[stage]
+    if pk is not None:
+        # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
+        ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
+                        ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
+    else:
+        q = A(T * hw, D)
+        gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
+                sA2=0, sC=hw * D)
+        att = A(T * hw, D)
+        ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+        _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
+                     w[bp + "norm2.bias"])
+    arx.release(m1)
+    ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx)
+    return tgt
 
-    # the stride-4 lateral branch: beside the coarser stages when a second fork is available, first otherwise
-    ar2, stream2 = fork2 if fork2 is not None else (None, None)
-    if ar2 is not None:
-        ar2.reset()
-    lat_fork = _Fork(stream2)
-    with lat_fork:
-        tgt1 = lateral(1, ar2 if ar2 is not None else ar)
+
+
+def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=None):
+    """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level.
+
+    The lateral branch of a level (_lateral) depends only on its input map and the text; only the top-down merge + 3x3
+    convolution chain is sequential (stage 4 -> 1).  lat1 = (fork, tgt) is the stride-4 lateral branch started early by
+    run_clip as a parallel graph branch; it is joined when the chain reaches stride 4."""
+    cfg, w = model.cfg, model._packed
+    A = ar.alloc
+    sizes = sc["sizes"]
+    pd = "pixel_decoder."
     y = None
     y_hw = None
     for stage in (4, 3, 2, 1):
@@ -609,11 +618,11 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, fork2
         hw = h * ww
         y_new = A(T * hw, D)
         m0 = ar.mark()
-        if stage == 1:
-            lat_fork.join()
-            tgt = tgt1
+        if stage == 1 and lat1 is not None:
+            lat1[0].join()
+            tgt = lat1[1]
         else:
-            tgt = lateral(stage, ar)
+            tgt = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, ar)
         # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
         if y is not None:
             ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
