@@ -169,6 +169,18 @@ int tce_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t n
 /*   tce_tile_f32       out[i] = src[i % n_src] for i < n_src*reps (row broadcast: memory_bus / sentence feature) */
 int tce_tile_f32(const float* src, float* out, int64_t n_src, int64_t reps, tceStream stream);
 int tce_sigmoid_f32(const float* x, float* out, int64_t n, tceStream stream);
+
+/* Several device-to-device copies in ONE launch: the staging of a captured graph's inputs and the clones of its output
+ * tensors (the reference hands back fresh tensors from forward(), tce_rvos.py:360-393; a replayed graph writes into
+ * fixed buffers, so each output is copied out -- as one kernel instead of one per tensor).  Sizes in 4-byte words;
+ * rows == 1 is a dense run, rows > 1 gathers `rows` runs of row_words from a source pitch into a dense destination. */
+#define TCE_COPY_MAX_SEGS 16
+typedef struct tceCopySeg {
+  const void* src;
+  void* dst;
+  int64_t rows, row_words, src_pitch_words;
+} tceCopySeg;
+int tce_copy_segments(const tceCopySeg* segs, int32_t n, tceStream stream);
 int tce_box_refine_f32(const float* tmp, const float* ref, float* out, int32_t n, int32_t ref_dim, tceStream stream);
 
 /* Dynamic mask head (tce_rvos.py:426-510,536-599), evaluated for `nl` decoder levels at once without

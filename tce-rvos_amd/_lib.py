@@ -40,6 +40,11 @@ class XattnArgs(C.Structure):
                 ("M", i32), ("batch", i32), ("a2_rows", i32), ("res_mode", i32), ("group", i32), ("eps_out", f32)]
 
 
+
+class CopySeg(C.Structure):
+    _fields_ = [("src", c_f), ("dst", c_f), ("rows", i64), ("row_words", i64), ("src_pitch_words", i64)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol of include/tce_rvos.h (tests check this)
 SIGNATURES = {
     "tce_abi_version": (i32, []),
@@ -71,6 +76,7 @@ SIGNATURES = {
     "tce_add_f32": (i32, [c_f, c_f, c_f, i64, i64, c_f]),
     "tce_tile_f32": (i32, [c_f, c_f, i64, i64, c_f]),
     "tce_sigmoid_f32": (i32, [c_f, c_f, i64, c_f]),
+    "tce_copy_segments": (i32, [C.POINTER(CopySeg), i32, c_f]),
     "tce_box_refine_f32": (i32, [c_f, c_f, c_f, i32, i32, c_f]),
     "tce_mask_pack_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_mask_tail_f32": (i32, [c_f, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, f32, f32, i32, c_f]),

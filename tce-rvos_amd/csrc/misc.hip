@@ -221,6 +221,31 @@ __global__ void __launch_bounds__(256) mask_tail_kernel(const float* __restrict_
   masks[((long long)item) * hw + pix] = o;
 }
 
+// One launch for a list of copies (the graph's input staging and the clones of its output tensors): blockIdx.y picks the
+// segment, blockIdx.x strides over it.  Dense 16-byte-aligned segments move as float4; anything else word by word.
+struct CopySegs {
+  tceCopySeg s[TCE_COPY_MAX_SEGS];
+};
+__global__ void __launch_bounds__(256) copy_segments_kernel(CopySegs segs) {
+  const tceCopySeg sg = segs.s[blockIdx.y];
+  const long long total = sg.rows * sg.row_words;
+  const long long stride = (long long)gridDim.x * 256;
+  const float* __restrict__ src = (const float*)sg.src;
+  float* __restrict__ dst = (float*)sg.dst;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (sg.rows == 1 && (((uintptr_t)sg.src | (uintptr_t)sg.dst) & 15) == 0) {
+    const long long quads = total >> 2;
+    for (long long q = i; q < quads; q += stride) ((float4*)dst)[q] = ((const float4*)src)[q];
+    for (long long t = (quads << 2) + i; t < total; t += stride) dst[t] = src[t];
+    return;
+  }
+  for (; i < total; i += stride) {
+    const long long r = i / sg.row_words, c = i - r * sg.row_words;
+    dst[i] = src[r * sg.src_pitch_words + c];
+  }
+}
+
+
 }  // namespace
 
 extern "C" int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F,
@@ -323,5 +348,22 @@ extern "C" int tce_mask_tail_f32(const float* G, const float* tail, const float*
   hipLaunchKernelGGL(mask_tail_kernel, dim3(tce_cdiv(h * w, 256), nl * T * Q), dim3(256), 0, (hipStream_t)stream, G,
                      tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px);
   TCE_CHECK_LAUNCH("tce_mask_tail_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_copy_segments(const tceCopySeg* segs, int32_t n, tceStream stream) {
+  TCE_CHECK_ARG(segs && n > 0 && n <= TCE_COPY_MAX_SEGS, "tce_copy_segments: 1..TCE_COPY_MAX_SEGS segments");
+  CopySegs pack;
+  long long biggest = 0;
+  for (int i = 0; i < n; ++i) {
+    TCE_CHECK_ARG(segs[i].src && segs[i].dst && segs[i].rows > 0 && segs[i].row_words > 0 &&
+                      (segs[i].rows == 1 || segs[i].src_pitch_words >= segs[i].row_words),
+                  "tce_copy_segments: bad segment");
+    pack.s[i] = segs[i];
+    biggest = std::max<long long>(biggest, (long long)segs[i].rows * segs[i].row_words);
+  }
+  const int gx = (int)std::min<long long>(1024, tce_cdiv(biggest, 1024));
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, pack);
+  TCE_CHECK_LAUNCH("tce_copy_segments");
   return TCE_OK;
 }

@@ -6,6 +6,7 @@ checkpoints load with `load_state_dict`); `forward` is NOT a module graph: it is
 that launches hand-written HIP kernels (libtce_rvos.so) on token-major / channels-last activations living in
 a bump arena.  PyTorch supplies device memory, the stream and the (third-party) RoBERTa text encoder.
 """
+import os
 import math
 from collections import OrderedDict
 from typing import List, Optional
@@ -509,7 +510,11 @@ class ReferFormer(nn.Module):
         with torch.cuda.graph(graph):
             out = fn(res)
         _ALL_GRAPHS.append(graph)  # executables outlive their cache entry (see _ALL_GRAPHS)
-        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel() + res[3].buf.numel())
+        try:
+            plan = ops.CopyPlan(_flat_outputs(out)) if os.environ.get("TCE_COPYPLAN", "1") != "0" else None
+        except ValueError:  # an output the segment copy cannot express: per-tensor clones
+            plan = None
+        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel() + res[3].buf.numel(), plan)
         self._graphs[key] = ent
         # LRU bound (entries and bytes); the entry just captured always stays.  Eviction returns the arenas.
         while len(self._graphs) > 1 and (len(self._graphs) > self.max_graphs or
@@ -530,11 +535,14 @@ class ReferFormer(nn.Module):
     def _replay(self, key, ent, inputs):
         self._graphs.move_to_end(key)
         graph, statics, out = ent[0], ent[1], ent[2]
-        for d_, s_ in zip(statics, inputs):
-            d_.copy_(s_)
+        ops.copy_many(statics, inputs)  # one launch stages the inputs ...
         graph.replay()
-        return {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in a.items()} for a in v])
-                for k, v in out.items()}
+        plan = ent[5]
+        if plan is None:
+            return {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in a.items()} for a in v])
+                    for k, v in out.items()}
+        it = iter(plan.clone())  # ... and one hands back fresh output tensors (same order as _flat_outputs)
+        return {k: (next(it) if torch.is_tensor(v) else [{kk: next(it) for kk in a} for a in v]) for k, v in out.items()}
 
     @torch.no_grad()
     def forward_text_encoder(self, captions, device):
@@ -558,6 +566,18 @@ class ReferFormer(nn.Module):
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
             ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res), frames)
         return self._replay(key, ent, (frames, text_hidden, text_pooled))
+
+
+def _flat_outputs(out):
+    """The tensors of forward()'s output dict in iteration order (aux_outputs: list of dicts)."""
+    flat = []
+    for v in out.values():
+        if torch.is_tensor(v):
+            flat.append(v)
+        else:
+            for a in v:
+                flat.extend(a.values())
+    return flat
 
 
 def is_frozen_bn_key(key):

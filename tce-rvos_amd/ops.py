@@ -417,6 +417,89 @@ def add(a, b, out=None, alloc=None):
     return out
 
 
+def _copy_seg(src):
+    """(rows, row_words, src_pitch_words) of a tensor the segment copy can move, or None."""
+    es = src.element_size()
+    if es % 4 or src.numel() == 0:
+        return None
+    k = es // 4
+    if src.is_contiguous():
+        return 1, src.numel() * k, src.numel() * k
+    if src.dim() < 2 or src.stride(-1) != 1:
+        return None
+    pitch = src.stride(-2)
+    exp = pitch * src.shape[-2]
+    for d in range(src.dim() - 3, -1, -1):  # leading dims must collapse onto the row pitch
+        if src.shape[d] != 1 and src.stride(d) != exp:
+            return None
+        exp *= src.shape[d] if src.shape[d] != 1 else 1
+    return src.numel() // src.shape[-1], src.shape[-1] * k, pitch * k
+
+
+class CopyPlan:
+    """A fixed list of source tensors copied out with one launch per 16 (tce_copy_segments): `clone()` returns fresh
+    dense tensors carved from one allocation."""
+
+    def __init__(self, srcs):
+        from ._lib import CopySeg
+        self.srcs = list(srcs)
+        self.geo = [_copy_seg(t) for t in self.srcs]
+        if any(g is None for g in self.geo):
+            raise ValueError("copy plan: a source is neither dense nor a uniform row gather of 4-byte words")
+        self.offs, off = [], 0
+        for t in self.srcs:
+            self.offs.append(off)
+            off += (t.numel() * t.element_size() + 255) // 256 * 256
+        self.total = off
+        self.segs = (CopySeg * len(self.srcs))()
+        for sg, t, (rows, rw, pitch) in zip(self.segs, self.srcs, self.geo):
+            sg.src, sg.rows, sg.row_words, sg.src_pitch_words = t.data_ptr(), rows, rw, pitch
+
+    def _launch(self):
+        from ._lib import CopySeg
+        n, st = len(self.srcs), _stream()
+        for lo in range(0, n, 16):
+            m = min(16, n - lo)
+            check(lib().tce_copy_segments(C.cast(C.byref(self.segs, lo * C.sizeof(CopySeg)), C.POINTER(CopySeg)), m, st),
+                  "tce_copy_segments")
+
+    def clone(self):
+        buf = torch.empty(self.total, dtype=torch.uint8, device=self.srcs[0].device)
+        base, outs = buf.data_ptr(), []
+        for sg, t, off in zip(self.segs, self.srcs, self.offs):
+            sg.dst = base + off
+            outs.append(buf[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape))
+        self._launch()
+        return outs
+
+
+def copy_many(dsts, srcs):
+    """dsts[i] <- srcs[i] (dense destinations of the same shape and dtype) in one launch per 16 tensors; tensors the
+    segment copy cannot express go through Tensor.copy_."""
+    from ._lib import CopySeg
+    segs, n = (CopySeg * 16)(), 0
+    st = _stream()
+
+    def flush():
+        nonlocal n
+        if n:
+            check(lib().tce_copy_segments(segs, n, st), "tce_copy_segments")
+        n = 0
+
+    for d, t in zip(dsts, srcs):
+        geo = _copy_seg(t) if (d.shape == t.shape and d.dtype == t.dtype and d.is_contiguous() and
+                               d.device == t.device) else None
+        if geo is None:
+            d.copy_(t)
+            continue
+        sg = segs[n]
+        sg.src, sg.dst, sg.rows, sg.row_words, sg.src_pitch_words = t.data_ptr(), d.data_ptr(), geo[0], geo[1], geo[2]
+        n += 1
+        if n == 16:
+            flush()
+    flush()
+
+
 def tile(src, reps, out=None, alloc=None):
     """out = src repeated `reps` times along a new leading axis (flattened)."""
     _chk(src, "src")

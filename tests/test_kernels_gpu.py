@@ -786,3 +786,25 @@ def test_xattn_fused_eight_key_groups_per_frame(ops):
     ops.xattn_fused(xd, pk, dev(mha.out_proj.bias.detach()), S, xd, a2=dev(pos), ln_out=(dev(gam), dev(bet)), batch=T,
                     sX=S * Cn, sOut=S * Cn, group=8, per_batch_weights=True)
     close(xd.view(T, S, Cn), ref, 3e-4, 3e-4)
+
+
+def test_copy_segments_plan_and_many(ops):
+    """tce_copy_segments: dense, misaligned, strided-row and int64 sources in one launch; > 16 segments split."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    base = torch.randn(40000, generator=g).cuda()
+    srcs = [base[:1000], base[1001:1008], base[2000:2600].view(1, 5, 30, 4)[..., :2], base[3:4],
+            torch.arange(37, device="cuda"), base[8192:8192 + 20000].view(100, 200)]
+    srcs += [base[i * 13:i * 13 + 11] for i in range(20)]
+    plan = ops.CopyPlan(srcs)
+    outs = plan.clone()
+    torch.cuda.synchronize()
+    for o, s_ in zip(outs, srcs):
+        assert o.shape == s_.shape and o.dtype == s_.dtype and o.is_contiguous()
+        assert torch.equal(o, s_)
+    dsts = [torch.zeros_like(s_, memory_format=torch.contiguous_format) for s_ in srcs]
+    ops.copy_many(dsts, srcs)
+    torch.cuda.synchronize()
+    for o, s_ in zip(dsts, srcs):
+        assert torch.equal(o, s_)
+    with pytest.raises(ValueError):
+        ops.CopyPlan([base[:100:3]])  # neither dense nor a row gather
