@@ -275,6 +275,17 @@ int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K);
 int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream);
 int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream);
 
+/* 3x3 convolution, stride 1, zero padding 1, 256 -> 256 channels on channels-last maps [T*H*W, 256]: the pixel
+ * decoder's output convolutions (CrossModalFPNDecoder, segmentation.py:186-204,253-283; nn.Conv2d(256, 256, 3,
+ * padding=1)) as a pixel-stationary kernel (csrc/chain.hip) -- each wave owns 32 pixels and all 256 output channels,
+ * the activations go from global memory straight into the MFMA operand registers, only the weights pass through LDS.
+ * w [256, 9*256] with k = (ky*3+kx)*256 + c (the layout tce_gemm_f32's implicit-GEMM mode takes); packed streams carry
+ * the rounding of the GEMM mode they were packed in (modes 1 and 2; mode 0 has no such kernel: use tce_gemm_f32). */
+int64_t tce_conv3x3_packed_bytes(int32_t Cin, int32_t N);
+int tce_conv3x3_pack_f32(const float* w, void* packed, int32_t Cin, int32_t N, tceStream stream);
+int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, const float* bias, float* out, int64_t ldo, int32_t T,
+                    int32_t H, int32_t W, int32_t Cin, int32_t N, tceStream stream);
+
 /* Cross-attention of a token tensor against a SHORT key sequence as ONE token-stationary launch (csrc/chain.hip):
  *     out = LN?( res (+|*) ( MHA(q = x + a2, k, v) W_o^T + b_o ) )          8 heads x 32 channels, `group` key slots
  * group 32: the L <= 32 text keys (VisionLanguageBlock / fusion module); group 8: the f_token = 8 frame tokens of

@@ -93,6 +93,9 @@ SIGNATURES = {
     "tce_rowlin_packed_bytes": (i64, [i32, i32]),
     "tce_rowlin_pack_f32": (i32, [c_f, i64, c_f, i32, i32, c_f]),
     "tce_rowlin_f32": (i32, [C.POINTER(RowLinArgs), c_f]),
+    "tce_conv3x3_packed_bytes": (i64, [i32, i32]),
+    "tce_conv3x3_pack_f32": (i32, [c_f, c_f, i32, i32, c_f]),
+    "tce_conv3x3_f32": (i32, [c_f, i64, c_f, c_f, c_f, i64, i32, i32, i32, i32, i32, c_f]),
     "tce_graph_begin": (i32, [c_f]),
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),

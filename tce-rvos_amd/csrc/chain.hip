@@ -900,6 +900,287 @@ __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 convolution, stride 1, zero padding 1, CIN -> 256 channels, channels-last (the pixel decoder's output
+// convolutions, segmentation.py:186-204,253-283).  Pixel-stationary: a wave owns 32 pixels (the MFMA columns) and all
+// 256 output channels (8 accumulator tiles); K = 9 taps x CIN runs in 16-wide steps, ordered (vertical tap, channel
+// chunk, horizontal tap) so that the three horizontal neighbours of a chunk are read in consecutive steps.
+//   * The pixel's own operand -- 16 input channels of the tap's neighbour -- goes from global memory straight into
+//     registers LX steps ahead (32 contiguous bytes per lane; out-of-image taps read a block of zeros instead) and is
+//     split into fp16 hi/lo between the previous step's MFMAs: the activations never pass through LDS.
+//   * The weight fragments of a step (8 channel tiles x hi/lo = 16 pieces of 1 KiB, pre-split and pre-ordered by
+//     tce_conv3x3_pack_f32) are requested LW steps ahead into registers, each wave a quarter of the stage, written into
+//     a 4-stage LDS ring two steps before use and read back by all waves as A fragments.
+//   * One barrier per step, placed after tile 5: by then every fragment of the stage is in registers (the stage can be
+//     refilled), and tiles 6 and 7 are issued behind the barrier so the LDS latency of the next step's first
+//     fragments hides under them.
+//   * All loads of the loop are issued by hand in a fixed order (per mid-step: the lane's two operand loads, then the
+//     wave's four weight loads), which makes the counted vmcnt at a mid-step exact.  They are all REGISTER loads on
+//     purpose: a first version streamed the weights with LDS-DMA (global_load_lds) next to register loads of the
+//     operand, and on real (not L2-resident) activations the counted wait let operand registers be read before their
+//     data had arrived -- register loads and LDS-DMA loads do not retire in issue order relative to each other, so one
+//     vmcnt cannot cover both.  (The FFN / row-linear kernels above count only DMA against DMA.)
+// Ablations (tools/conv3_ablate.py, profiles/r02_conv3x3.txt): MFMA + LDS alone run at 1.4 PFLOP/s issued; the loads
+// cost as much again because the L2 -> CU traffic (every workgroup streams the 2.4 MB of weights, every tap re-reads
+// its pixels) is throughput-bound at the clock the MFMAs leave.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CONV_PAD_STAGES = 6;  // = the kernel's weight lead LW
+
+struct ConvArgs {
+  const float* x;
+  const unsigned char* wpk;
+  const float* bias;
+  float* out;
+  long long ldx, ldo;
+  int H, W, M;
+  int* range_flag;
+  int single;
+};
+
+// Ablation builds (tools/conv3_ablate.py, -DCONV_ABL=n; results are then wrong): bit 0: one workgroup per CU; bit 1: no
+// barrier inside the loop; bit 2: no MFMA (fragments kept live); bit 3: no weight DMA inside the loop; bit 4: no operand
+// loads inside the loop.
+#ifndef CONV_ABL
+#define CONV_ABL 0
+#endif
+
+template <int BYTE_OFF>
+__device__ __forceinline__ void gload16(f32x4& dst, const float* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(BYTE_OFF) : "memory");
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int CIN, bool SINGLE>
+__global__ void __launch_bounds__(256, 1) conv3x3_kernel(const ConvArgs p) {
+  constexpr int WAVES = 4, NTL = 8;
+  constexpr int STAGE = 2 * NTL * PIECE;  // one k-step of weights: 16 KiB
+  constexpr int R = 4;                    // LDS ring stages
+  constexpr int XS = 6, LX = XS + 1;      // operand ring slots (registers); the operand of step q is requested at mid-step q-LX
+  constexpr int NW = CONV_PAD_STAGES - 2, LW = NW + 2;      // weight stages in flight (registers); those of step s are requested at mid-step s-LW
+  constexpr int INFLIGHT = 6 * (LW - 3);  // loads younger than the weights a mid-step waits for (2 operand + 4 weight per mid-step)
+  constexpr int BODY = 12;                // unrolled steps: 4 channel chunks x 3 horizontal taps (lcm of 3 and R)
+  constexpr int ITERS = 3 * (CIN / 64);   // (vertical tap, group of 4 chunks)
+  constexpr int KS = BODY * ITERS;
+  static_assert(CIN % 64 == 0, "channel chunks come in groups of four");
+  static_assert(BODY % R == 0 && BODY % XS == 0 && BODY % NW == 0 && LX >= LW, "ring positions are compile-time");
+  static_assert(WAVES * WT_BYTES <= R * STAGE, "the epilogue's staging tiles alias the ring");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[R * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hf = lane >> 5;
+  const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
+
+  // this lane's pixel; per (vertical tap, chunk group) the addresses of its three horizontal neighbours' channels, or
+  // of the zero block behind the weights for taps outside the image
+  const int m = m0 + (lane & 31);
+  const int px = m % p.W, py = (m / p.W) % p.H;
+  const float* const zeros = reinterpret_cast<const float*>(p.wpk + (long long)(KS + CONV_PAD_STAGES) * STAGE) + 8 * hf;
+  const float* const xme = p.x + (long long)min(m, p.M - 1) * p.ldx + 8 * hf;
+  auto iter_ptrs = [&](const int it, const float* (&q)[3]) {
+    const int dy = it / (CIN / 64) - 1, cq = it % (CIN / 64);
+    const bool row_ok = it < ITERS && m < p.M && (unsigned)(py + dy) < (unsigned)p.H;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool ok = row_ok && (unsigned)(px + d - 1) < (unsigned)p.W;
+      q[d] = (ok ? xme + (long long)(dy * p.W + d - 1) * p.ldx : zeros) + 64 * cq;
+    }
+  };
+
+  // weights: this wave moves pieces 4*wave .. 4*wave+3 of every stage (4 KiB, one float4 per lane and piece) through
+  // registers into the ring
+  const float* wp = reinterpret_cast<const float*>(p.wpk + (long long)(4 * wave) * PIECE + lane * 16);
+  unsigned char* const wdst = smem + (4 * wave) * PIECE + lane * 16;
+  f32x4 wr[NW][4];
+  auto wload = [&](f32x4 (&dst)[4]) {
+    if (!(CONV_ABL & 8)) {
+      gload16<0>(dst[0], wp);
+      gload16<PIECE>(dst[1], wp);
+      gload16<2 * PIECE>(dst[2], wp);
+      gload16<3 * PIECE>(dst[3], wp);
+    }
+    wp += STAGE / 4;
+  };
+  auto wstore = [&](const f32x4 (&src)[4], const int stage) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wdst + stage * STAGE + q * PIECE) = src[q];
+  };
+
+  f32x4 xr[XS][2];
+  const float* cur[3];
+  const float* nxt[3];
+  iter_ptrs(0, cur);
+  iter_ptrs(1, nxt);
+  // operand of body step JJ (>= BODY: of the next iteration) -> ring slot
+  auto xload = [&](auto jjc, f32x4 (&dst)[2]) {
+    constexpr int JJ = decltype(jjc)::value;
+    constexpr int J = JJ % BODY;
+    const float* const src = JJ < BODY ? cur[J % 3] : nxt[J % 3];
+    if (CONV_ABL & 16) return;
+    gload16<64 * (J / 3)>(dst[0], src);
+    gload16<64 * (J / 3) + 16>(dst[1], src);
+  };
+  // "every load up to n operations ago has landed"; the register tuples named here are what the following code reads
+  auto wait_loads = [&](auto nc, f32x4 (&xs)[2], f32x4 (&ws)[4]) {
+    constexpr int N = (CONV_ABL & 24) ? 0 : decltype(nc)::value;
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(xs[0]), "+v"(xs[1]), "+v"(ws[0]), "+v"(ws[1]), "+v"(ws[2]), "+v"(ws[3])
+                 : "n"(N)
+                 : "memory");
+  };
+  using nfl = std::integral_constant<int, INFLIGHT>;
+
+  // prologue = mid-steps -LX .. -1 in the loop's own order (wait + ring write of step m+2, then the requests)
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  h16x8 bh, bl;
+  static_for<0, LX>([&](auto mc) {
+    constexpr int m = decltype(mc)::value - LX;
+    if constexpr (m + 2 >= 0) {
+      wait_loads(nfl{}, xr[(m + 2) % XS], wr[(m + 2) % NW]);
+      wstore(wr[(m + 2) % NW], (m + 2) % R);
+      if constexpr (m + 2 == 0) {  // operand 0 (two mid-steps older than these weights) feeds step 0 directly
+        const float f[8] = {xr[0][0][0], xr[0][0][1], xr[0][0][2], xr[0][0][3], xr[0][1][0], xr[0][1][1], xr[0][1][2], xr[0][1][3]};
+        const HL b = split8(f, SINGLE ? 1 : 0);
+        bh = b.hi;
+        bl = b.lo;
+        asm volatile("" : "+v"(bh), "+v"(bl));  // the split reads xr[0] before a later request reuses it
+      }
+    }
+    if constexpr (m + LX >= 0) xload(std::integral_constant<int, m + LX>{}, xr[(m + LX) % XS]);
+    if constexpr (m + LW >= 0) wload(wr[(m + LW) % NW]);
+  });
+  __syncthreads();
+  h16x8 fh[4], fl[4];
+  {
+    const unsigned char* const st = smem + lane * 16;
+    fh[0] = *reinterpret_cast<const h16x8*>(st);
+    fl[0] = *reinterpret_cast<const h16x8*>(st + PIECE);
+    fh[1] = *reinterpret_cast<const h16x8*>(st + 2 * PIECE);
+    fl[1] = *reinterpret_cast<const h16x8*>(st + 3 * PIECE);
+  }
+
+  for (int it = 0; it < ITERS; ++it) {
+    static_for<0, BODY>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int nslot = (j + 1) % XS;  // operand of the next step: split under this step's first four tiles
+      const unsigned char* const st = smem + (j % R) * STAGE + lane * 16;
+      unsigned nh[4], nl[4];
+      auto tile = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+#if CONV_ABL & 4
+        const h16x8 k0 = fh[t % 4], k1 = fl[t % 4], k2 = bh, k3 = bl;
+        asm volatile("" : : "v"(k0), "v"(k1), "v"(k2), "v"(k3));
+#else
+        if constexpr (!SINGLE) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t % 4], bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t % 4], bh, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t % 4], bh, acc[t], 0, 0, 0);
+#endif
+      };
+      // tiles 0..5, the fragments two tiles ahead of their MFMAs (tiles 0 and 1 were fetched by the previous step)
+      static_for<0, 6>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        fh[(t + 2) % 4] = *reinterpret_cast<const h16x8*>(st + (2 * t + 4) * PIECE);
+        fl[(t + 2) % 4] = *reinterpret_cast<const h16x8*>(st + (2 * t + 5) * PIECE);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(tc);
+        if constexpr (t < 4) {
+          const float a = xr[nslot][t >> 1][2 * (t & 1)], b = xr[nslot][t >> 1][2 * (t & 1) + 1];
+          if constexpr (SINGLE) {
+            nh[t] = __builtin_bit_cast(unsigned, fp16x2_t{(__fp16)a, (__fp16)b});
+            nl[t] = 0u;
+          } else {
+            const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
+            nh[t] = __builtin_bit_cast(unsigned, h);
+            nl[t] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+          }
+          asm volatile("" : "+v"(nh[t]), "+v"(nl[t]));  // keeps the split here (it is only consumed by the next step)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // Mid-step: every fragment of this stage is in registers.  The weights of step j+2 (requested LW-2 mid-steps ago)
+      // go into their stage -- free since the barrier of mid-step j-2 -- and the barrier publishes the stage written
+      // one mid-step ago and releases this one.  Tiles 6 and 7 are issued AFTER the barrier so that the LDS latency
+      // of the next step's first fragments hides under them.
+      wait_loads(nfl{}, xr[(j + 2) % XS], wr[(j + 2) % NW]);
+      wstore(wr[(j + 2) % NW], (j + 2) % R);
+      if (!(CONV_ABL & 2)) __syncthreads();
+      xload(std::integral_constant<int, j + LX>{}, xr[(j + LX) % XS]);
+      wload(wr[(j + LW) % NW]);
+      {
+        const unsigned char* const sn = smem + ((j + 1) % R) * STAGE + lane * 16;
+        fh[0] = *reinterpret_cast<const h16x8*>(sn);
+        fl[0] = *reinterpret_cast<const h16x8*>(sn + PIECE);
+        fh[1] = *reinterpret_cast<const h16x8*>(sn + 2 * PIECE);
+        fl[1] = *reinterpret_cast<const h16x8*>(sn + 3 * PIECE);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      tile(std::integral_constant<int, 6>{});
+      tile(std::integral_constant<int, 7>{});
+      __builtin_amdgcn_sched_barrier(0);
+      bh = __builtin_bit_cast(h16x8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+      bl = __builtin_bit_cast(h16x8, u32x4{nl[0], nl[1], nl[2], nl[3]});
+    });
+#pragma unroll
+    for (int d = 0; d < 3; ++d) cur[d] = nxt[d];
+    iter_ptrs(it + 2, nxt);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (padding) loads
+  __syncthreads();
+
+  float* const wt = reinterpret_cast<float*>(smem + wave * WT_BYTES);
+  tce_amax_t amax = 0;
+  const ResTile none = {};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    tile_bias_res<0>(acc[t], tile_bias_load(p.bias, 32 * t, lane), none, wt, lane);
+    tile_store(acc[t], p.out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
+  }
+  tce_range_report(p.range_flag, amax);
+}
+
+// w [256, 9*CIN] (k = tap*CIN + c) -> 9*CIN/16 + 4 stages of 16 pieces in the kernel's K order: stage s = 12*it + j is
+// vertical tap dy = it / (CIN/64), channel chunk cc = 4*(it % (CIN/64)) + j/3, horizontal tap dx = j % 3 (the three
+// horizontal neighbours of a chunk in consecutive steps: they share cache lines).  Piece 2t (+1) = hi (lo) fragment of
+// channel tile t: lane (r, hf) holds w[32t + r][(3dy+dx)*CIN + 16cc + 8hf + 0..7].  CONV_PAD_STAGES trailing stages of
+// zeros (the weight requests run that many steps ahead) and 2 KiB of zeros that out-of-image taps read as their operand.
+__global__ void __launch_bounds__(256) conv3x3_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                           const int CIN, const long long units, const int single) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int lane = (int)(u & 63);
+  const long long pg = u >> 6;
+  const int piece = (int)(pg & 15);
+  const long long s = pg >> 4;
+  const int r = lane & 31, hf = lane >> 5, t = piece >> 1;
+  u32x4 o = {0u, 0u, 0u, 0u};
+  if (s < 9 * CIN / 16) {
+    const int it = (int)(s / 12), j = (int)(s % 12);
+    const int dy = it / (CIN / 64), cc = 4 * (it % (CIN / 64)) + j / 3, dx = j % 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[(long long)(32 * t + r) * (9 * CIN) + (3 * dy + dx) * CIN + 16 * cc + 8 * hf + e];
+    const HL f = split8(v, single);
+    o = __builtin_bit_cast(u32x4, (piece & 1) ? f.lo : f.hi);
+  }
+  reinterpret_cast<u32x4*>(out)[u] = o;
+}
+
+inline bool conv3x3_shape_ok(int Cin, int N) { return Cin == 256 && N == 256; }
+inline long long conv3x3_units(int Cin) { return (long long)(9 * Cin / 16 + CONV_PAD_STAGES) * 16 * 64 + 128; }
+
 }  // namespace
 
 extern "C" int tce_debug_ffn_set_stamp_buffer(long long* dev_buf) {
@@ -1043,5 +1324,35 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   else if (q.K == 128) rowlin_launch<128>(a, batch, row, s);
   else rowlin_launch<96>(a, batch, row, s);
   TCE_CHECK_LAUNCH("tce_rowlin_f32");
+  return TCE_OK;
+}
+
+extern "C" int64_t tce_conv3x3_packed_bytes(int32_t Cin, int32_t N) { return conv3x3_shape_ok(Cin, N) ? conv3x3_units(Cin) * 16 : -1; }
+
+extern "C" int tce_conv3x3_pack_f32(const float* w, void* packed, int32_t Cin, int32_t N, tceStream stream) {
+  TCE_CHECK_ARG(conv3x3_shape_ok(Cin, N), "tce_conv3x3_pack_f32: unsupported shape Cin=%d N=%d (256 -> 256)", Cin, N);
+  TCE_CHECK_ARG(w && packed && tce_aligned16(packed), "tce_conv3x3_pack_f32: null / misaligned pointer");
+  const long long units = conv3x3_units(Cin);
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned char*)packed, Cin, units, tce_gemm_single_pass());
+  TCE_CHECK_LAUNCH("tce_conv3x3_pack_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, const float* bias, float* out, int64_t ldo,
+                               int32_t T, int32_t H, int32_t W, int32_t Cin, int32_t N, tceStream stream) {
+  TCE_CHECK_ARG(conv3x3_shape_ok(Cin, N), "tce_conv3x3_f32: unsupported shape Cin=%d N=%d (256 -> 256)", Cin, N);
+  TCE_CHECK_ARG(x && packed && out && T > 0 && H > 0 && W > 0 && (long long)T * H * W < (1ll << 31),
+                "tce_conv3x3_f32: null pointer or bad sizes");
+  TCE_CHECK_ARG(ldx >= Cin && ldx % 4 == 0 && ldo >= N && ldo % 4 == 0, "tce_conv3x3_f32: bad row pitch");
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(packed) && (!bias || tce_aligned16(bias)),
+                "tce_conv3x3_f32: pointers must be 16-byte aligned");
+  ConvArgs a;
+  a.x = x; a.wpk = (const unsigned char*)packed; a.bias = bias; a.out = out;
+  a.ldx = ldx; a.ldo = ldo; a.H = H; a.W = W; a.M = T * H * W;
+  a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  if (a.single) hipLaunchKernelGGL((conv3x3_kernel<256, true>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv3x3_kernel<256, false>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  TCE_CHECK_LAUNCH("tce_conv3x3_f32");
   return TCE_OK;
 }

@@ -261,6 +261,11 @@ class ReferFormer(nn.Module):
                 t = w[k]
                 if torch.is_tensor(t) and t.dtype == torch.float32 and t.dim() == 2 and (k.endswith("weight") or k.endswith(".w")):
                     ops.rowlin_register(t)
+            # pixel-stationary 3x3 convolution (csrc/chain.hip): the pixel decoder's 256 -> 256 output convolutions
+            ops.CONV3_TABLE.clear()
+            for k in list(w):
+                if k.startswith("pixel_decoder.") and k.endswith(".weight:cl") and w[k].shape[1] % 9 == 0:
+                    ops.conv3x3_register(w[k], w[k].shape[1] // 9)
             if cfg.is_resnet:
                 self._pack_resnet(sd, w)
             if cfg.video:

@@ -237,6 +237,11 @@ def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = T * Ho * Wo
+    if (kh == 3 and kw == 3 and stride == 1 and pad == 1 and act == ACT_NONE and res_mode == RES_NONE and splitk == 1
+            and M >= CONV3_MIN_PIXELS and get_gemm_mode() != "f32"):
+        pk = CONV3_TABLE.get((w_packed.data_ptr(), N, w_packed.shape[1]))
+        if pk is not None and x.stride(0) % 4 == 0:
+            return conv3x3(x, pk, T, H, W, Cin, N, bias=bias, out=out, alloc=alloc), Ho, Wo
     if out is None:
         out = alloc(M, N) if alloc else torch.empty(M, N, dtype=torch.float32, device=x.device)
     g = GemmArgs()
@@ -732,6 +737,55 @@ def rowlin(x, pk, out, M, N, K, ldx, ldo, bias=None, a2=None, lda2=0, a2_rows=0,
     go()
     e1.record()
     GEMM_PROFILE.append((f"rowlin_kernel<{K}", False, 2.0 * M * N * K * batch, e0, e1))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3x3 / stride 1 / pad 1 convolution 256 -> 256 as a pixel-stationary launch (csrc/chain.hip: tce_conv3x3_f32)
+# ---------------------------------------------------------------------------------------------------------------
+CONV3_TABLE = {}  # (data_ptr, N, K) of a model-owned [N, 9*Cin] weight -> packed stream
+CONV3_MIN_PIXELS = int(os.environ.get("TCE_CONV3_MIN_PIXELS", 12000))
+
+
+def conv3x3_pack(w_cl, Cin):
+    """w_cl [N, 9*Cin], k = (ky*3+kx)*Cin + c."""
+    _chk(w_cl, "w")
+    N = w_cl.shape[0]
+    nbytes = lib().tce_conv3x3_packed_bytes(Cin, N)
+    if nbytes < 0 or w_cl.shape[1] != 9 * Cin or not w_cl.is_contiguous():
+        raise ValueError(f"conv3x3_pack: unsupported shape N={N} Cin={Cin}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_cl.device)
+    check(lib().tce_conv3x3_pack_f32(w_cl.data_ptr(), out.data_ptr(), Cin, N, _stream()), "tce_conv3x3_pack_f32")
+    return out
+
+
+def conv3x3_register(w_cl, Cin):
+    if lib().tce_conv3x3_packed_bytes(Cin, w_cl.shape[0]) < 0 or w_cl.shape[1] != 9 * Cin:
+        return None
+    key = (w_cl.data_ptr(), w_cl.shape[0], w_cl.shape[1])
+    if key not in CONV3_TABLE:
+        CONV3_TABLE[key] = conv3x3_pack(w_cl, Cin)
+    return CONV3_TABLE[key]
+
+
+def conv3x3(x, pk, T, H, W, Cin, N, bias=None, out=None, alloc=None):
+    """x [T*H*W, Cin] channels-last -> [T*H*W, N]."""
+    _chk(x, "x")
+    M = T * H * W
+    if out is None:
+        out = alloc(M, N) if alloc else torch.empty(M, N, dtype=torch.float32, device=x.device)
+
+    def go():
+        check(lib().tce_conv3x3_f32(x.data_ptr(), x.stride(0), pk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    out.data_ptr(), out.stride(0), T, H, W, Cin, N, _stream()), "tce_conv3x3_f32")
+    if GEMM_PROFILE is None:
+        go()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    GEMM_PROFILE.append((f"conv3x3_kernel<{Cin}", True, 2.0 * M * N * 9 * Cin, e0, e1))
     return out
 
 

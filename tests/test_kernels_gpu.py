@@ -808,3 +808,24 @@ def test_copy_segments_plan_and_many(ops):
         assert torch.equal(o, s_)
     with pytest.raises(ValueError):
         ops.CopyPlan([base[:100:3]])  # neither dense nor a row gather
+
+
+@pytest.mark.parametrize("T,H,W", [(1, 9, 13), (2, 32, 40), (1, 45, 80), (3, 17, 5)])
+def test_conv3x3_pixel_stationary(ops, T, H, W):
+    """tce_conv3x3_f32 (pixel-stationary kernel) against torch conv2d in fp64 and against the implicit-GEMM path;
+    image borders, a ragged last pixel block and pixels whose 3x3 neighbourhood crosses frames."""
+    g = torch.Generator(device="cpu").manual_seed(11 + H)
+    x = torch.randn(T, 256, H, W, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    b = torch.randn(256, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(T * H * W, 256)
+    x_cl = x.permute(0, 2, 3, 1).reshape(T * H * W, 256).contiguous().cuda()
+    w_cl = w.permute(0, 2, 3, 1).reshape(256, -1).contiguous().cuda()
+    pk = ops.conv3x3_pack(w_cl, 256)
+    out = ops.conv3x3(x_cl, pk, T, H, W, 256, 256, bias=b.cuda())
+    gem, _, _ = ops.conv2d_cl(x_cl, w_cl, T, H, W, 256, 3, 3, 1, 1, bias=b.cuda())
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (out.double().cpu() - ref).abs().max().item() < 2e-6 * scale * 8
+    assert (out - gem).abs().max().item() < 2e-6 * scale * 8
