@@ -731,8 +731,8 @@ __global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs 
       tile_bias_res<2>(acc, bt, rt, wt, lane);
     }
   };
-  // the half just multiplied may be overwritten and the next one must have landed: this wave's DMAs of the half after
-  // next (SLOTS of them) plus `younger` later operations (a tile's 4 stores) may stay in flight
+  // the half just multiplied may be overwritten and the next one must have landed: only this wave's DMAs of the half
+  // after next (SLOTS of them) may stay in flight
   auto tile_mma = [&](f32x16& acc, const bool stores_follow) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -770,11 +770,14 @@ __global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs 
       const BiasTile bt = tile_bias_load(p.bias, 32 * t, lane);
       f32x16 acc;
       tile_mma(acc, true);
+      // Only the DMAs of the half after next are younger than what must have landed, and DMAs retire in issue order
+      // among themselves -- so this count is exact.  The wait sits BEFORE the tile's stores on purpose: loads and
+      // stores do not retire in order relative to each other, and with the stores in front of it a count of
+      // SLOTS + 4 could be satisfied by early store acknowledgements while a needed DMA was still in flight.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+      __syncthreads();
       finish_tile(acc, bt, rt);
       tile_store(acc, out, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
-      // older than this tile's 4 stores: the DMAs of the half after next (may fly on) and everything that must be done
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS + 4) : "memory");
-      __syncthreads();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
