@@ -6,6 +6,8 @@ form the implicit-GEMM convolutions read.  The encoder sequence of a frame is th
 levels (S rows), so `memory` is [T, S, 256] exactly as the reference returns it.  Position maps are frame
 independent for un-padded clips and are shared by all frames through frame-batched launches (stride 0).
 """
+import os
+
 import torch
 
 from . import ops
@@ -220,20 +222,34 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     if Fk > 0:
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
+    # free between the text join and the decoder fork
+    tok_stream = side_stream if os.environ.get("TCE_TOKFORK", "1") != "0" else None
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
-             ar=ar, norm=None):
-        """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D]."""
+             ar=ar, norm=None, small_fork=None):
+        """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D].
+        ref may be a callable (evaluated beside value_proj when small_fork is a _Fork: the few-row projections of the
+        frame-token path run as a parallel branch next to the large value projection)."""
         A = ar.alloc
         m1 = ar.mark()
-        value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
         proj = A(q_rows, 384)
-        if q_pos_shared:  # position map shared by all frames: frame-batched launch, stride 0 on the addend
-            gemm_ex(query, w[pre + "offaw.weight"], proj, q_per_frame, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
-                    a2=q_pos, lda2=D, batch=T, sA=q_per_frame * D, sA2=0, sC=q_per_frame * 384)
+
+        def offaw():
+            if q_pos_shared:  # position map shared by all frames: frame-batched launch, stride 0 on the addend
+                gemm_ex(query, w[pre + "offaw.weight"], proj, q_per_frame, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
+                        a2=q_pos, lda2=D, batch=T, sA=q_per_frame * D, sA2=0, sC=q_per_frame * 384)
+            else:
+                gemm_ex(query, w[pre + "offaw.weight"], proj, q_rows, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
+                        a2=q_pos, lda2=D)
+        if small_fork is not None:
+            with small_fork:
+                ref = ref()
+                offaw()
+        value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
+        if small_fork is not None:
+            small_fork.join()
         else:
-            gemm_ex(query, w[pre + "offaw.weight"], proj, q_rows, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
-                    a2=q_pos, lda2=D)
+            offaw()
         samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
                               out=A(q_rows, D))
         if norm:
@@ -249,16 +265,23 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         if Fk > 0:
             fp = lp + "ftoken_layers."
             m0 = ar.mark()
-            # (1) tokens gather from their frame by MSDA (:447-454)
-            r = _lin(A, token, T * Fk, D, w[fp + "reference_points.weight"], w[fp + "reference_points.bias"], 2)
-            ref = ops.sigmoid(r, out=A(T * Fk, 2))
-            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, ref, 2, True, token, norm=fp + "norm1")
+            # The token path is ~16 launches on T*F (= 40) rows, each a kernel boundary long and on the critical path
+            # between two encoder layers: independent ones run as parallel graph branches (tok_stream).
+            # (1) tokens gather from their frame by MSDA (:447-454); reference points / offsets beside value_proj
+            def token_ref():
+                r = _lin(A, token, T * Fk, D, w[fp + "reference_points.weight"], w[fp + "reference_points.bias"], 2)
+                return ops.sigmoid(r, out=A(T * Fk, 2))
+            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, token_ref, 2, True, token,
+                 norm=fp + "norm1", small_fork=_Fork(tok_stream))
             # (2) all T*F tokens attend to each other (:463-469)
             pre = fp + "token_self_atten."
             qk = A(T * Fk, 2 * D)
+            fk_v = _Fork(tok_stream)
+            with fk_v:
+                v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
             gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
                     batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
-            v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            fk_v.join()
             att = A(T * Fk, D)
             ops.mha_core(qk, qk[:, D:], v, 1, NH, T * Fk, T * Fk, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
             gemm_ex(att, w[pre + "out_proj.weight"], token, T * Fk, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
@@ -267,9 +290,12 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             # (3) every pixel attends to the F tokens of its own frame (:480-484)
             pre = fp + "frame_token_atten."
             k = A(T * Fk, D)
+            fk_v = _Fork(tok_stream)
+            with fk_v:
+                v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
             gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
                     sA=Fk * D, sA2=0, sC=Fk * D)
-            v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            fk_v.join()
             if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
                 # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
                 # launch (the keys / values differ per frame: one folded weight stream per frame)
