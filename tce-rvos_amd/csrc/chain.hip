@@ -1184,6 +1184,95 @@ __global__ void __launch_bounds__(256) conv3x3_pack_kernel(const float* __restri
 inline bool conv3x3_shape_ok(int Cin, int N) { return Cin == 256 && N == 256; }
 inline long long conv3x3_units(int Cin) { return (long long)(9 * Cin / 16 + CONV_PAD_STAGES) * 16 * 64 + 128; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Swin patch embedding (swin_transformer.py:433-471: Conv2d(3, C, 4, stride 4) + LayerNorm) on the matrix cores: a wave
+// takes 32 patches as MFMA columns, K = 3 x 4 x 4 = 48 taps in three 16-wide steps whose order puts one input channel
+// per step (k = 16c + 4ky + kx), so a lane reads two 16-byte row segments of its patch per step straight into the
+// operand registers; the C x 48 weight is split into fragments once per wave and stays in registers.  Bias, LayerNorm
+// over the C channels a lane pair holds, and full-line stores.  HBM-bound (reads the clip once, writes [tokens, C]).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256) patch_embed_mfma_kernel(const float* __restrict__ frames, const float* __restrict__ w,
+                                                               const float* __restrict__ b, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ out,
+                                                               const int H, const int W, const float eps, const int ntok,
+                                                               const int Hp, const int Wp, int* const range_flag,
+                                                               const int single) {
+  constexpr int C = 32 * NT;
+  __shared__ __attribute__((aligned(16))) unsigned char wtbuf[4 * WT_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hf = lane >> 5;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  if (m0 >= ntok) return;  // no workgroup-wide barrier below
+  float* const wt = reinterpret_cast<float*>(wtbuf + wave * WT_BYTES);
+
+  // this lane's patch: rows 4py + 2hf + {0,1} of every channel
+  const int tok = min(m0 + r, ntok - 1);
+  const int t = tok / (Hp * Wp), rem = tok - t * (Hp * Wp);
+  const int py = rem / Wp, px = rem - py * Wp;
+  const bool vec = ((W & 3) == 0) && (px * 4 + 3 < W);
+  f32x4 raw[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int yy = py * 4 + 2 * hf + q;
+      const float* const row = frames + (((long long)t * 3 + c) * H + min(yy, H - 1)) * W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yy < H) {
+        if (vec) {
+          v = *reinterpret_cast<const f32x4*>(row + px * 4);
+        } else {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx)
+            if (px * 4 + kx < W) v[kx] = row[px * 4 + kx];
+        }
+      }
+      raw[c][q] = v;
+    }
+  // weight fragments: lane (r, hf) holds w[32t + r][16s + 8hf + 0..7]
+  h16x8 ah[NT][3], al[NT][3];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int sK = 0; sK < 3; ++sK) {
+      const float* const pw = w + (long long)(32 * tt + r) * 48 + 16 * sK + 8 * hf;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pw), c4 = *reinterpret_cast<const f32x4*>(pw + 4);
+      const float f[8] = {a[0], a[1], a[2], a[3], c4[0], c4[1], c4[2], c4[3]};
+      const HL sp = split8(f, single);
+      ah[tt][sK] = sp.hi;
+      al[tt][sK] = sp.lo;
+    }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+#pragma unroll
+  for (int sK = 0; sK < 3; ++sK) {
+    const float f[8] = {raw[sK][0][0], raw[sK][0][1], raw[sK][0][2], raw[sK][0][3],
+                        raw[sK][1][0], raw[sK][1][1], raw[sK][1][2], raw[sK][1][3]};
+    const HL x = split8(f, single);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      if (!single) {
+        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt][sK], x.lo, acc[tt], 0, 0, 0);
+        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt][sK], x.hi, acc[tt], 0, 0, 0);
+      }
+      acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt][sK], x.hi, acc[tt], 0, 0, 0);
+    }
+  }
+  const ResTile none = {};
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) tile_bias_res<0>(acc[tt], tile_bias_load(b, 32 * tt, lane), none, wt, lane);
+  rows_layernorm<NT>(acc, gamma, beta, eps, hf);
+  tce_amax_t amax = 0;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) tile_store(acc[tt], out, C, m0, ntok, 32 * tt, wt, lane, amax);
+  tce_range_report(range_flag, amax);
+}
+
 }  // namespace
 
 extern "C" int tce_debug_ffn_set_stamp_buffer(long long* dev_buf) {
@@ -1358,4 +1447,19 @@ extern "C" int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, 
   else hipLaunchKernelGGL((conv3x3_kernel<256, false>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
   TCE_CHECK_LAUNCH("tce_conv3x3_f32");
   return TCE_OK;
+}
+
+// split-fp16 / fp16 modes of tce_patch_embed_f32 (norm.hip dispatches here); false = shape not covered
+bool tce_patch_embed_mfma(const float* frames, const float* w, const float* b, const float* gamma, const float* beta,
+                          float* out, int H, int W, int C, float eps, long long ntok, int Hp, int Wp, hipStream_t s) {
+  if ((C != 96 && C != 128 && C != 192) || ntok >= (1ll << 31) || !tce_aligned16(frames) || !tce_aligned16(out) ||
+      !tce_aligned16(w) || !tce_aligned16(b) || !tce_aligned16(gamma) || !tce_aligned16(beta))
+    return false;
+  const dim3 grid(tce_cdiv(ntok, 128)), block(256);
+  int* const rf = tce_range_flag();
+  const int single = tce_gemm_single_pass();
+  if (C == 96) hipLaunchKernelGGL((patch_embed_mfma_kernel<3>), grid, block, 0, s, frames, w, b, gamma, beta, out, H, W, eps, (int)ntok, Hp, Wp, rf, single);
+  else if (C == 128) hipLaunchKernelGGL((patch_embed_mfma_kernel<4>), grid, block, 0, s, frames, w, b, gamma, beta, out, H, W, eps, (int)ntok, Hp, Wp, rf, single);
+  else hipLaunchKernelGGL((patch_embed_mfma_kernel<6>), grid, block, 0, s, frames, w, b, gamma, beta, out, H, W, eps, (int)ntok, Hp, Wp, rf, single);
+  return true;
 }

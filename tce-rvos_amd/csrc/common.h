@@ -16,6 +16,8 @@ int* tce_range_flag();
 // 1 when tce_set_gemm_mode(2) is active: the fp16 kernels issue ONE MFMA per product on operands rounded to nearest
 // fp16 (fp32 accumulate) instead of the three of the hi/lo split (defined in gemm.hip)
 int tce_gemm_single_pass();
+bool tce_patch_embed_mfma(const float* frames, const float* w, const float* b, const float* gamma, const float* beta,
+                          float* out, int H, int W, int C, float eps, long long ntok, int Hp, int Wp, hipStream_t s);
 
 #define TCE_CHECK_ARG(cond, ...)            \
   do {                                      \

@@ -516,6 +516,13 @@ extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const fl
   TCE_CHECK_ARG(T > 0 && H > 0 && W > 0 && C > 0 && C <= 256, "tce_patch_embed_f32: need 0 < C <= 256 (C=%d)", C);
   const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
   const long long ntok = (long long)T * Hp * Wp;
+  // split-fp16 / fp16 GEMM modes: the taps go through the matrix cores (csrc/chain.hip); exact-fp32 mode keeps the
+  // fp32 vector kernels below
+  if (tce_get_gemm_mode() != 0 &&
+      tce_patch_embed_mfma(frames, w, b, gamma, beta, out, H, W, C, eps, ntok, Hp, Wp, (hipStream_t)stream)) {
+    TCE_CHECK_LAUNCH("tce_patch_embed_f32");
+    return TCE_OK;
+  }
   if (C % 8 == 0 && C <= 152 && tce_aligned16(frames) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta)) {
     constexpr int TOK = 128;  // tokens (= threads) per workgroup: 52 KiB of LDS at C = 96 -> three workgroups per CU
     const size_t lds = (size_t)(TOK * (C + 4) + 2 * TOK) * sizeof(float);

@@ -156,8 +156,16 @@ def test_patch_embed(ops, T, H, W, C):
     xp = F.pad(x, (0, (4 - W % 4) % 4, 0, (4 - H % 4) % 4))
     ref = F.conv2d(xp, w, b, stride=4).flatten(2).transpose(1, 2)
     ref = F.layer_norm(ref, (C,), ga, be)
-    out, Hp, Wp = ops.patch_embed(dev(x), dev(w), dev(b), dev(ga), dev(be))
+    out, Hp, Wp = ops.patch_embed(dev(x), dev(w), dev(b), dev(ga), dev(be))  # MFMA kernel for C in 96/128/192
     close(out.view(T, Hp * Wp, C), ref, 1e-4, 1e-4)
+    try:  # exact-fp32 mode keeps the fp32 vector kernels
+        ops.set_gemm_mode("f32")
+        out32, _, _ = ops.patch_embed(dev(x), dev(w), dev(b), dev(ga), dev(be))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_mode("f16x3")
+    close(out32.view(T, Hp * Wp, C), ref, 1e-4, 1e-4)
+    assert (out32 - out).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("T,H,W,nH,shift", [(2, 18, 25, 3, 0), (2, 18, 25, 3, 3), (1, 9, 13, 6, 3), (1, 7, 7, 1, 3),
