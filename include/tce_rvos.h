@@ -139,6 +139,15 @@ int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_sh
                                    int32_t S, int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P,
                                    tceStream stream);
 
+/* Backward of the same op -- MultiScaleDeformableAttention_update.ms_deform_attn_backward (vision.cpp:13-16,
+ * ms_deform_attn_cuda.cu:105-186, ms_deform_im2col_cuda.cuh:87-160,457-1229): grad_output [N,Lq,M*D] ->
+ * grad_value [N,S,M,D] (zero-filled here, then accumulated with fp32 atomics: summation order, like the reference's, is
+ * not deterministic), grad_sampling_loc [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P].  Any D, L, P. */
+int tce_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                                    float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int32_t N,
+                                    int32_t S, int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P, tceStream stream);
+
 /* Fused form used by the model: takes the raw projection output proj [N*Lq, M*L*P*3] = (sampling offsets
  * [M,L,P,2] | attention logits [M,L*P]) and the reference points ref [N,Lq,ref_dim] (level-independent,
  * valid_ratios == 1), does softmax over L*P, the offset normalisation (ref_dim 2: / (W_l,H_l); ref_dim 4:

@@ -227,6 +227,21 @@ def msda_core(value: Tensor, shapes: List[Tuple[int, int]], loc: Tensor, weights
     return out.reshape(N, Lq, M * D)
 
 
+def msda_core_backward(value: Tensor, shapes: List[Tuple[int, int]], loc: Tensor, weights: Tensor,
+                       grad_out: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """Gradients of msda_core wrt (value, loc, weights) for a given grad_out [N,Lq,M*D]: what the native backward returns
+    (ms_deform_attn_cuda.cu:105-186; per-corner rule ms_deform_im2col_cuda.cuh:87-160).  msda_core is built from
+    differentiable torch ops whose derivative IS that rule (floor and the in-range masks carry no gradient; d/dx of the
+    bilinear weights gives hh (v2 - v1) + lh (v4 - v3), scaled by W through x = loc_x * W - 0.5), so autograd states it."""
+    with torch.enable_grad():
+        v = value.detach().clone().requires_grad_(True)
+        p = loc.detach().clone().requires_grad_(True)
+        w = weights.detach().clone().requires_grad_(True)
+        out = msda_core(v, shapes, p, w)
+        gv, gp, gw = torch.autograd.grad(out, (v, p, w), grad_out.reshape(out.shape))
+    return gv, gp, gw
+
+
 def msda_module(sd: Dict[str, Tensor], pre: str, query: Tensor, ref: Tensor, src: Tensor,
                 shapes: List[Tuple[int, int]], padding_mask: Optional[Tensor], M: int, L: int, P: int):
     """MSDeformAttn.forward, ops/modules/ms_deform_attn.py:79-117.  Returns (out, sampling_locations, weights)."""

@@ -69,6 +69,7 @@ SIGNATURES = {
     "tce_patch_merge_ln_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
     "tce_mha_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, c_f, f32, c_f]),
     "tce_ms_deform_attn_forward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_ms_deform_attn_backward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_msda_fused_f32": (i32, [c_f, c_f, c_f, c_f, C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_pos_sine2d_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),

@@ -460,6 +460,86 @@ __global__ void __launch_bounds__(256) msda_generic_dev_kernel(const float* __re
   out[idx] = acc;
 }
 
+// Backward of the reference-signature op (ms_deform_attn_cuda.cu:105-186, ms_deform_im2col_cuda.cuh:87-160,457-1229):
+// 32 lanes own one (n, query, head) and walk its L*P samples; a lane owns the channels c = lane, lane+32, ... .  Per
+// sample and channel the reference's rule: with top = grad_out[c] * attn_weight,
+//     grad_value[corner] += bilinear_weight(corner) * top                              (atomic: queries collide)
+//     grad_attn          += grad_out[c] * (w1 v1 + w2 v2 + w3 v3 + w4 v4)
+//     grad_loc.x         += W * top * (hh (v2 - v1) + lh (v4 - v3)),   grad_loc.y += H * top * (hw (v3 - v1) + lw (v4 - v2))
+// where a corner outside the map contributes v = 0 and no atomic, and a sample outside (-1, H) x (-1, W) contributes
+// nothing.  The three per-sample sums are reduced over the 32 lanes with shuffles (the reference reduces over the
+// thread block in shared memory) and written by lane 0, so grad_loc / grad_attn need no zero fill.
+__global__ void __launch_bounds__(256) msda_backward_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                            const int64_t* __restrict__ starts, const float* __restrict__ loc,
+                                                            const float* __restrict__ aw, const float* __restrict__ gout,
+                                                            float* __restrict__ gvalue, float* __restrict__ gloc,
+                                                            float* __restrict__ gattn, int S, int M, int Dh, int Lq, int L, int P,
+                                                            long long items) {
+  const int l32 = threadIdx.x & 31;
+  const long long item = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;  // (n*Lq + q)*M + m
+  if (item >= items) return;  // uniform over the 32 lanes
+  const int m = (int)(item % M);
+  const int n = (int)(item / M / Lq);
+  const long long row_stride = (long long)M * Dh;
+  const long long vbase = (long long)n * S * row_stride + (long long)m * Dh;
+  const float* const go = gout + item * Dh;
+  for (int l = 0; l < L; ++l) {
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const long long lbase = vbase + starts[l] * row_stride;
+    for (int pt = 0; pt < P; ++pt) {
+      const long long sidx = item * (L * P) + l * P + pt;
+      const float x = loc[2 * sidx], y = loc[2 * sidx + 1], a = aw[sidx];
+      const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+      float g_w = 0.f, g_h = 0.f, g_a = 0.f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= Wl - 1;
+        const bool ok3 = h_high <= Hl - 1 && w_low >= 0, ok4 = h_high <= Hl - 1 && w_high <= Wl - 1;
+        const long long p1 = lbase + ((long long)h_low * Wl + w_low) * row_stride;
+        const long long p2 = p1 + row_stride, p3 = p1 + (long long)Wl * row_stride, p4 = p3 + row_stride;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        for (int c = l32; c < Dh; c += 32) {
+          const float tg = go[c], top = tg * a;
+          float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+          if (ok1) {
+            v1 = value[p1 + c];
+            atomicAdd(gvalue + p1 + c, w1 * top);
+          }
+          if (ok2) {
+            v2 = value[p2 + c];
+            atomicAdd(gvalue + p2 + c, w2 * top);
+          }
+          if (ok3) {
+            v3 = value[p3 + c];
+            atomicAdd(gvalue + p3 + c, w3 * top);
+          }
+          if (ok4) {
+            v4 = value[p4 + c];
+            atomicAdd(gvalue + p4 + c, w4 * top);
+          }
+          g_a += tg * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+          g_w += top * (hh * (v2 - v1) + lh * (v4 - v3));
+          g_h += top * (hw * (v3 - v1) + lw * (v4 - v2));
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        g_w += __shfl_xor(g_w, o, 32);
+        g_h += __shfl_xor(g_h, o, 32);
+        g_a += __shfl_xor(g_a, o, 32);
+      }
+      if (l32 == 0) {
+        gloc[2 * sidx] = (float)Wl * g_w;
+        gloc[2 * sidx + 1] = (float)Hl * g_h;
+        gattn[sidx] = g_a;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -486,6 +566,30 @@ extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t*
   hipLaunchKernelGGL(msda_plain_dev_kernel, dim3(tce_cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, Lq, L, P, total);
   TCE_CHECK_LAUNCH("tce_ms_deform_attn_forward_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                               const int64_t* level_start_index, const float* sampling_loc,
+                                               const float* attn_weight, const float* grad_output, float* grad_value,
+                                               float* grad_sampling_loc, float* grad_attn_weight, int32_t N, int32_t S,
+                                               int32_t M, int32_t Dh, int32_t Lq, int32_t L, int32_t P, tceStream stream) {
+  TCE_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && grad_output && grad_value &&
+                    grad_sampling_loc && grad_attn_weight,
+                "tce_ms_deform_attn_backward_f32: null pointer");
+  TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Dh > 0 && Lq > 0 && L > 0 && P > 0, "tce_ms_deform_attn_backward_f32: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  // grad_value is accumulated with atomics (the reference starts from at::zeros_like(value), ms_deform_attn_cuda.cu:142)
+  const hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * Dh * sizeof(float), s);
+  if (e != hipSuccess) {
+    tce_set_error("tce_ms_deform_attn_backward_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+    return TCE_ELAUNCH;
+  }
+  const long long items = (long long)N * Lq * M;
+  hipLaunchKernelGGL(msda_backward_kernel, dim3(tce_cdiv(items * 32, 256)), dim3(256), 0, s, value, spatial_shapes,
+                     level_start_index, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
+                     grad_attn_weight, S, M, Dh, Lq, L, P, items);
+  TCE_CHECK_LAUNCH("tce_ms_deform_attn_backward_f32");
   return TCE_OK;
 }
 

@@ -377,6 +377,49 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step=64):
+    """Drop-in for MultiScaleDeformableAttention_update.ms_deform_attn_backward (ms_deform_attn_func.py:36-41):
+    returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"), (grad_output, "grad_output")):
+        _chk(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} tensor has to be contiguous")
+    if not (spatial_shapes.is_cuda and level_start_index.is_cuda and spatial_shapes.dtype == torch.int64):
+        raise RuntimeError("spatial_shapes / level_start_index must be CUDA int64 tensors")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    if grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must be [N, Lq, M*D]")
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    check(lib().tce_ms_deform_attn_backward_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                                sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                                gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), N, S, M, D, Lq, L, P, _stream()),
+          "tce_ms_deform_attn_backward_f32")
+    return gv, gl, ga
+
+
+class MSDeformAttnFunction(torch.autograd.Function):
+    """The reference's autograd wrapper (models/ops/functions/ms_deform_attn_func.py:20-43) over the HIP op: same
+    argument list, same returned gradients (value, -, -, sampling_locations, attention_weights, -)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=64, is_3d=False):
+        ctx.im2col_step = im2col_step
+        out = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                     attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None, None
+
+
 def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_frame, out=None, alloc=None):
     _chk(value, "value")
     if out is None:

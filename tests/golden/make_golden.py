@@ -7,7 +7,8 @@ Needs /root/reference (read-only) -- never runs on the GPU box.  The files it wr
 Fixtures
   msda_cases.npz       reference MSDA core (ms_deform_attn_func.py:67-87) on the reference's own
                        test case (models/ops/test.py:21-26, seed 3) + cases with out-of-range
-                       sampling locations and a realistic slice
+                       sampling locations and a realistic slice; forward outputs and the gradients
+                       wrt value / locations / weights for a seeded grad_output
   interp_cases.npz     F.interpolate nearest / bilinear(align_corners=False) at the odd size pairs
                        the model hits (12x20->23x40, 23x40->11x20 ...)
   e2e_swin_t_small.npz full ReferFormer.forward of the reference, real Swin-T architecture, T=3, 72x100
@@ -75,6 +76,13 @@ def gen_msda():
         out[f"c{i}_loc"] = _np(loc)
         out[f"c{i}_w"] = _np(w)
         out[f"c{i}_out"] = _np(o)
+        # gradients of the reference's own core (autograd through its grid_sample formulation) for a seeded grad_output:
+        # the pin of the backward op (the reference's test checks its CUDA backward against exactly this, test.py:60-86)
+        torch.manual_seed(100 + i)
+        go = torch.randn_like(o)
+        v_, l_, w_ = (t.clone().requires_grad_(True) for t in (value, loc, w))
+        gv, gl, gw = torch.autograd.grad(ms_deform_attn_core_pytorch(v_, shapes, l_, w_), (v_, l_, w_), go)
+        out[f"c{i}_gout"], out[f"c{i}_gvalue"], out[f"c{i}_gloc"], out[f"c{i}_gw"] = _np(go), _np(gv), _np(gl), _np(gw)
     out["n_cases"] = np.asarray(len(cases))
     np.savez_compressed(os.path.join(HERE, "msda_cases.npz"), **out)
 

@@ -257,6 +257,42 @@ def test_msda_reference_op_matches_reference_fixture(ops):
     assert 2 in dims and 32 in dims
 
 
+def test_msda_backward_matches_reference_fixture(ops):
+    """tce_ms_deform_attn_backward_f32 against gradients of the reference's own core (golden fixture; D = 2 and D = 32,
+    out-of-range samples); grad_value sums atomically, hence the small absolute slack."""
+    fx = load_npz("msda_cases.npz")
+    for i in range(int(fx["n_cases"])):
+        shapes = torch.from_numpy(fx[f"c{i}_shapes"])
+        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        t = lambda k: dev(torch.from_numpy(fx[f"c{i}_{k}"]))
+        gv, gl, gw = ops.ms_deform_attn_backward(t("value"), shapes.cuda(), lsi.cuda(), t("loc"), t("w"), t("gout"))
+        for got, key in ((gv, "gvalue"), (gl, "gloc"), (gw, "gw")):
+            ref = torch.from_numpy(fx[f"c{i}_{key}"])
+            close(got, ref, 1e-4, 1e-5 * max(1.0, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("N,Lq,M,Dh,L,P", [(2, 17, 3, 30, 2, 3), (1, 9, 2, 71, 3, 2), (2, 5, 8, 64, 4, 4), (1, 300, 8, 32, 4, 4)])
+def test_msda_autograd_function_generic_shapes(ops, N, Lq, M, Dh, L, P):
+    """The autograd wrapper (the reference's MSDeformAttnFunction interface) on head dims of the reference's own gradient
+    test (models/ops/test.py:85-86) against the oracle's backward; many queries colliding on few value rows."""
+    g = torch.Generator().manual_seed(7 * N + Dh + L * P)
+    shapes = torch.tensor([(6 + 2 * l, 5 + 3 * l) for l in range(L)][::-1], dtype=torch.int64)
+    S = int(shapes.prod(1).sum())
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, Dh, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.6 - 0.3
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    go = torch.randn(N, Lq, M * Dh, generator=g)
+    v, p, w = (dev(x).requires_grad_(True) for x in (value, loc, aw))
+    out = ops.MSDeformAttnFunction.apply(v, shapes.cuda(), lsi.cuda(), p, w, 64)
+    out.backward(dev(go))
+    rv, rp, rw = O.msda_core_backward(value.double(), [(int(h), int(ww)) for h, ww in shapes], loc.double(), aw.double(),
+                                      go.double())
+    close(out.detach(), O.msda_core(value, [(int(h), int(ww)) for h, ww in shapes], loc, aw), 1e-4, 1e-5)
+    for got, ref in ((v.grad, rv), (p.grad, rp), (w.grad, rw)):
+        close(got, ref.float(), 1e-4, 2e-5 * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("N,Lq,M,Dh,L,P", [(2, 50, 8, 32, 4, 8),     # L*P = 32: dword row-gather kernel
                                            (1, 33, 4, 32, 8, 8),     # L*P = 64: generic kernel
                                            (2, 17, 3, 30, 2, 3), (1, 9, 2, 71, 3, 2), (2, 5, 8, 64, 4, 4),  # test.py:85-86 dims

@@ -19,6 +19,20 @@ def test_msda_core_matches_reference_cases():
         assert torch.allclose(out, ref, rtol=1e-4, atol=1e-6), (i, (out - ref).abs().max())
 
 
+def test_msda_core_backward_matches_reference_gradients():
+    """The oracle's statement of the native backward (ms_deform_attn_cuda.cu:105-186) against gradients of the
+    reference's own core for a seeded grad_output (the comparison the reference's test makes for its CUDA op,
+    models/ops/test.py:60-86)."""
+    fx = load_npz("msda_cases.npz")
+    for i in range(int(fx["n_cases"])):
+        shapes = [tuple(int(v) for v in r) for r in fx[f"c{i}_shapes"]]
+        gv, gl, gw = O.msda_core_backward(torch.from_numpy(fx[f"c{i}_value"]), shapes, torch.from_numpy(fx[f"c{i}_loc"]),
+                                          torch.from_numpy(fx[f"c{i}_w"]), torch.from_numpy(fx[f"c{i}_gout"]))
+        for got, key in ((gv, "gvalue"), (gl, "gloc"), (gw, "gw")):
+            ref = torch.from_numpy(fx[f"c{i}_{key}"])
+            assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * max(1.0, ref.abs().max().item())), (i, key, (got - ref).abs().max())
+
+
 def test_interpolation_restatements_match_pytorch():
     fx = load_npz("interp_cases.npz")
     for i in range(int(fx["n_pairs"])):
