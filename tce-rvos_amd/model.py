@@ -493,10 +493,10 @@ class ReferFormer(nn.Module):
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
             return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot))
-        arena, side_arena, side_stream, arena2, stream2 = res
-        import os
+        arena, side_arena, side_stream, arena2, stream2, arena3, stream3, arena4, stream4 = res
         return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False,
-                        fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None)
+                        fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
+                        fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
     def _capture(self, key, statics, fn, like):
         """Captures fn((arena, side_arena, side_stream)) into a graph; the arenas belong to the graph (their
@@ -508,6 +508,12 @@ class ReferFormer(nn.Module):
                torch.cuda.Stream(device=like.device),
                # third branch: the pixel decoder's stride-4 lateral path (tgt + its self-attention / FFN temporaries)
                ops.Arena(like.device, int(tok0 * 4 * (2048 * 1.1 + 256 * 4)) + (64 << 20)),
+               torch.cuda.Stream(device=like.device),
+               # fourth / fifth branch: the stride-32 lateral path + the merge chain down to stride 16 (tokens/64 and
+               # tokens/16 maps, two-GEMM FFN hidden [tokens/16 ... , 2048]); the stride-16 lateral path
+               ops.Arena(like.device, int(tok0 / 64 * 4 * (2048 + 256 * 12)) + int(tok0 / 16 * 4 * 256 * 8) + (64 << 20)),
+               torch.cuda.Stream(device=like.device),
+               ops.Arena(like.device, int(tok0 / 16 * 4 * (2048 * 1.1 + 256 * 12)) + (64 << 20)),
                torch.cuda.Stream(device=like.device))
         fn(None if False else res)  # eager warm-up on the same resources: builds per-shape constants, lazy inits
         torch.cuda.synchronize()
@@ -519,7 +525,7 @@ class ReferFormer(nn.Module):
             plan = ops.CopyPlan(_flat_outputs(out)) if os.environ.get("TCE_COPYPLAN", "1") != "0" else None
         except ValueError:  # an output the segment copy cannot express: per-tensor clones
             plan = None
-        ent = (graph, statics, out, res, res[0].buf.numel() + res[1].buf.numel() + res[3].buf.numel(), plan)
+        ent = (graph, statics, out, res, sum(r.buf.numel() for r in res if isinstance(r, ops.Arena)), plan)
         self._graphs[key] = ent
         # LRU bound (entries and bytes); the entry just captured always stays.  Eviction returns the arenas.
         while len(self._graphs) > 1 and (len(self._graphs) > self.max_graphs or

@@ -75,14 +75,16 @@ class _Fork:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
-def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None):
+def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
+             fork3=None):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
     beside the pixel decoder's large kernels; it needs its own arena because both branches allocate.
     clone_outputs=False returns views into the arenas (valid until the arenas are used again): the graph path owns its
     arenas and copies the outputs out once per replay, so a second copy inside the graph would be wasted.
-    fork2 = (arena, stream): a third concurrent branch for the pixel decoder's stride-4 lateral path (see there)."""
+    fork2 = (arena, stream): a third concurrent branch for the pixel decoder's stride-4 lateral path (see there).
+    fork3 = ((arena, stream), (arena, stream)): two more for its stride-32 / stride-16 lateral paths (_pixel_decoder)."""
     cfg, w = model.cfg, model._packed
     dev = frames.device
     T, _, H0, W0 = frames.shape
@@ -406,7 +408,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
-    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1, par=fork3)
     dec_fork.join()
 
     _stage("pixel decoder")
@@ -627,19 +629,56 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
 
 
 
-def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=None):
+def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=None, par=None):
     """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level.
 
     The lateral branch of a level (_lateral) depends only on its input map and the text; only the top-down merge + 3x3
     convolution chain is sequential (stage 4 -> 1).  lat1 = (fork, tgt) is the stride-4 lateral branch started early by
-    run_clip as a parallel graph branch; it is joined when the chain reaches stride 4."""
+    run_clip as a parallel graph branch; it is joined when the chain reaches stride 4.  par = ((arena, stream),
+    (arena, stream)): the stride-32 lateral + the chain down to stride 16 and the stride-16 lateral run as two more
+    parallel branches beside the stride-8 lateral (the largest of the three) on the main stream."""
     cfg, w = model.cfg, model._packed
     A = ar.alloc
     sizes = sc["sizes"]
     pd = "pixel_decoder."
+
+    def merge_conv(tgt, stage, y, y_hw, arx, y_new):
+        """top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU -> y_new"""
+        h, ww = sizes[stage - 1]
+        if y is not None:
+            ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
+        conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=arx.alloc)
+        ops.groupnorm_cl(conv, w[f"{pd}layer_{stage}.norm.weight"], w[f"{pd}layer_{stage}.norm.bias"], T, h * ww, D, 8,
+                         relu=True, out=y_new, alloc=arx.alloc)
+
     y = None
     y_hw = None
-    for stage in (4, 3, 2, 1):
+    stages = (4, 3, 2, 1)
+    if par is not None and par[0][1] is not None and par[1][1] is not None:
+        (ar3, st3), (ar4, st4) = par
+        ar3.reset()
+        ar4.reset()
+        fk_l3 = _Fork(st4)
+        with fk_l3:
+            tgt3 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 3, ar4)
+        fk_c = _Fork(st3)
+        with fk_c:
+            (h4, w4), (h3, w3) = sizes[3], sizes[2]
+            y4, y3 = ar3.alloc(T * h4 * w4, D), ar3.alloc(T * h3 * w3, D)
+            tgt4 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 4, ar3)
+            merge_conv(tgt4, 4, None, None, ar3, y4)
+            fk_l3.join()  # this branch waits for the stride-16 lateral
+            merge_conv(tgt3, 3, y4, (h4, w4), ar3, y3)
+        h, ww = sizes[1]
+        y2 = A(T * h * ww, D)
+        m0 = ar.mark()
+        tgt2 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 2, ar)
+        fk_c.join()
+        merge_conv(tgt2, 2, y3, (h3, w3), ar, y2)
+        ar.release(m0)
+        y, y_hw = y2, (h, ww)
+        stages = (1,)
+    for stage in stages:
         h, ww = sizes[stage - 1]
         hw = h * ww
         y_new = A(T * hw, D)
@@ -649,12 +688,7 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
             tgt = lat1[1]
         else:
             tgt = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, ar)
-        # top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU
-        if y is not None:
-            ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
-        conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=A)
-        ops.groupnorm_cl(conv, w[f"{pd}layer_{stage}.norm.weight"], w[f"{pd}layer_{stage}.norm.bias"], T, hw, D, 8,
-                         relu=True, out=y_new, alloc=A)
+        merge_conv(tgt, stage, y, y_hw, ar, y_new)
         ar.release(m0)
         y, y_hw = y_new, (h, ww)
     h, ww = sizes[0]
