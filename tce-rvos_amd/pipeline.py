@@ -131,7 +131,57 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("start")
     # ------------------------------------------------------------------ backbone
-    feats = (_resnet_backbone if cfg.is_resnet else _swin_backbone)(model, frames, ar, sizes)
+    # input_proj + early fusion of a level (:258-307) needs that level's backbone map and the text only: with the extra
+    # branches of fork3 the two large levels start as soon as their Swin stage is done, beside the later stages (which
+    # work on few tokens); the two small ones follow the backbone, each on its own stream.
+    chs = cfg.num_channels
+    early = (fork3 is not None and not cfg.is_resnet and fork3[0][1] is not None and fork3[1][1] is not None and
+             side_stream is not None and os.environ.get("TCE_EARLY_PROJ", "1") != "0")
+    src = A(T * S, D) if early else None  # [T, S, 256]: the encoder sequence
+    lvl_forks = []
+
+    def input_level(l, feat, A):
+        h, ww = lvl_sizes[l]
+        hw = h * ww
+        if l < 3:
+            s = _lin(A, feat, T * hw, chs[1 + l], w[f"input_proj.{l}.0.weight"], w[f"input_proj.{l}.0.bias"], D)
+        else:
+            h5, w5 = sizes[3]
+            # 300 output rows against K = 9*C5 (6912): 20 workgroups would walk the whole K extent one after the other
+            k5 = 9 * chs[3]
+            sk = next((c for c in (8, 6, 4, 3, 2) if k5 % (c * 32) == 0), 1) if T * h * ww <= 2048 else 1
+            s, ho, wo = ops.conv2d_cl(feat, w["input_proj.3.0.weight:cl"], T, h5, w5, chs[3], 3, 3, 2, 1,
+                                      bias=w["input_proj.3.0.bias"], alloc=A, splitk=sk,
+                                      ws=A(sk * T * h * ww * D) if sk > 1 else None)
+            assert (ho, wo) == (h, ww)
+        s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
+        if fpk is not None and T * hw >= ops.XATTN_MIN_ROWS:
+            # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]
+            ops.xattn_fused(s, fpk, w["fusion_module.multihead_attn.out_proj.bias"], hw, src[starts[l]:], res_mode=RES_MUL,
+                            batch=T, sX=hw * D, sRes=hw * D, sOut=S * D)
+        else:
+            q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
+            att = A(T * hw, D)
+            ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
+            gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
+                    bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
+                    sA=hw * D, sC=S * D, sRes=hw * D)
+
+    on_stage = None
+    if early:
+        for arx, _ in fork3:
+            arx.reset()
+
+        def on_stage(i, feat):
+            if i in (1, 2):
+                arx, stx = fork3[i - 1]
+                fk_ = _Fork(stx)
+                with fk_:
+                    text_fork.join()  # this level's stream waits for the text branch (keys / values of the fusion)
+                    input_level(i - 1, feat, arx.alloc)
+                lvl_forks.append(fk_)
+    feats = _resnet_backbone(model, frames, ar, sizes) if cfg.is_resnet else _swin_backbone(model, frames, ar, sizes, on_stage)
 
     _stage("backbone")
     text_fork.join()
@@ -174,45 +224,21 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         with lat1_fork:
             lat1 = (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2))
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
-    src = A(T * S, D)  # [T, S, 256]: the encoder sequence
-    chs = cfg.num_channels
-    # The four levels are independent (they write disjoint slices of src): level 0 stays on the main stream, levels 1-3
-    # run as a parallel graph branch on the side stream, which is idle here (the text branch has joined, the decoder
-    # branch has not started).  No buffer is released before the branch has joined, so concurrent levels never share
-    # memory.
+    # The four levels are independent (they write disjoint slices of src).  Without the early start: level 0 on the main
+    # stream, levels 1-3 as one parallel branch on the side stream (idle here: the text branch has joined, the decoder
+    # branch has not started).  No buffer is released before the branches have joined.
+    if src is None:
+        src = A(T * S, D)
     m_levels = ar.mark()
-    lvl_forks = []
-    for l, lvl_stream in ((1, side_stream), (2, side_stream), (3, side_stream), (0, None)):
-        h, ww = lvl_sizes[l]
-        hw = h * ww
+    if early:
+        todo = ((2, side_stream), (3, None))
+    else:
+        todo = ((1, side_stream), (2, side_stream), (3, side_stream), (0, None))
+    for l, lvl_stream in todo:
         fk_ = _Fork(lvl_stream)
         lvl_forks.append(fk_)
-        fk_.__enter__()
-        if l < 3:
-            s = _lin(A, feats[1 + l], T * hw, chs[1 + l], w[f"input_proj.{l}.0.weight"], w[f"input_proj.{l}.0.bias"], D)
-        else:
-            h5, w5 = sizes[3]
-            # 300 output rows against K = 9*C5 (6912): 20 workgroups would walk the whole K extent one after the other
-            k5 = 9 * chs[3]
-            sk = next((c for c in (8, 6, 4, 3, 2) if k5 % (c * 32) == 0), 1) if T * h * ww <= 2048 else 1
-            s, ho, wo = ops.conv2d_cl(feats[3], w["input_proj.3.0.weight:cl"], T, h5, w5, chs[3], 3, 3, 2, 1,
-                                      bias=w["input_proj.3.0.bias"], alloc=A, splitk=sk,
-                                      ws=A(sk * T * h * ww * D) if sk > 1 else None)
-            assert (ho, wo) == (h, ww)
-        s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
-        if fpk is not None and T * hw >= ops.XATTN_MIN_ROWS:
-            # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]
-            ops.xattn_fused(s, fpk, w["fusion_module.multihead_attn.out_proj.bias"], hw, src[starts[l]:], res_mode=RES_MUL,
-                            batch=T, sX=hw * D, sRes=hw * D, sOut=S * D)
-        else:
-            q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
-            att = A(T * hw, D)
-            ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-            # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
-            gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
-                    bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
-                    sA=hw * D, sC=S * D, sRes=hw * D)
-        fk_.__exit__(None, None, None)
+        with fk_:
+            input_level(l, feats[min(1 + l, 3)], A)
     for fk_ in lvl_forks:
         fk_.join()
     ar.release(m_levels)
@@ -440,7 +466,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     return out
 
 
-def _swin_backbone(model, frames, ar, sizes):
+def _swin_backbone(model, frames, ar, sizes, on_stage=None):
     """swin_transformer.py:595-617: returns the four normed stage maps, token-major [T*h*w, C_i].
     Video-Swin (video_swin_transformer.py:678-697): same program with the 3-D window kernel, the (1,4,4) patch
     conv applied per frame, stage outputs taken before the merge and WITHOUT an output norm."""
@@ -502,6 +528,8 @@ def _swin_backbone(model, frames, ar, sizes):
         else:
             ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i)
             feats.append(out_i)
+        if on_stage is not None:
+            on_stage(i, feats[-1])  # the stage's map is final: work that needs only this map may start beside the rest
         if x_next is not None:
             m0 = ar.mark()
             p = f"{b}downsamples.{i}." if cfg.video else f"{b}layers.{i}.downsample."
