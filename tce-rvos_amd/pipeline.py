@@ -131,6 +131,30 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     _stage("start")
     # ------------------------------------------------------------------ backbone
+    def ln_(x, pre):
+        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
+
+    fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
+
+    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
+        """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
+        (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
+        pk = w.get(pre + "ffn:pk") if fused_ok else None
+        if pk is not None and M >= FFN_FUSED_MIN_ROWS:
+            ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
+                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
+            return
+        A = ar.alloc
+        m1 = ar.mark()
+        hdn = A(M, ff)
+        gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
+        sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
+        gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
+                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
+        ar.release(m1)
+        if norm:
+            ln_(x, norm)
+
     # input_proj + early fusion of a level (:258-307) needs that level's backbone map and the text only: with the extra
     # branches of fork3 the two large levels start as soon as their Swin stage is done, beside the later stages (which
     # work on few tokens); the two small ones follow the backbone, each on its own stream.
@@ -168,6 +192,8 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                     bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
                     sA=hw * D, sC=S * D, sRes=hw * D)
 
+    ar2, stream2 = fork2 if fork2 is not None else (None, None)
+    lat1 = None
     on_stage = None
     if early:
         for arx, _ in fork3:
@@ -187,42 +213,22 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     text_fork.join()
     _stage("text join")
 
-    def ln_(x, pre):
-        return ops.layernorm(x, w[pre + ".weight"], w[pre + ".bias"], 1e-5, out=x)
-
-    fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
-
-    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
-        """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
-        (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
-        pk = w.get(pre + "ffn:pk") if fused_ok else None
-        if pk is not None and M >= FFN_FUSED_MIN_ROWS:
-            ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
-                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
-            return
-        A = ar.alloc
-        m1 = ar.mark()
-        hdn = A(M, ff)
-        gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
-        sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
-        gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
-                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
-        ar.release(m1)
-        if norm:
-            ln_(x, norm)
-
     # ------------------------------------------------------------------ pixel decoder, stride-4 lateral branch, EARLY
     # adapter_1 + GroupNorm + VisionLanguageBlock at stride 4 read the backbone's C2 map and the text only -- not the
     # encoder memory (segmentation.py:187-196 with the backbone feature as the last lateral input) -- so this millisecond
-    # of work starts here, as a parallel graph branch beside input_proj and the whole encoder (whose frame-token chains
-    # and MSDA gathers leave the matrix cores idle), and is joined when the top-down chain reaches stride 4.
-    ar2, stream2 = fork2 if fork2 is not None else (None, None)
-    lat1 = None
-    if ar2 is not None and stream2 is not None:
+    # of work is a parallel graph branch, joined when the top-down chain reaches stride 4.
+    def start_lat1():
         ar2.reset()
         lat1_fork = _Fork(stream2)
         with lat1_fork:
-            lat1 = (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2))
+            return (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2))
+    # When it starts is a trade: its long kernels (72000-row cross-attention, FFN, GEMMs) slow down whatever runs beside
+    # them, and it must be done when the chain reaches stride 4.  Measured at config 2 (ms per clip): right after Swin
+    # stage 0 8.09, after the backbone 7.44, after encoder layer 0 / 1 / 2 / 3 (of 4) 7.41 / 7.37 / 7.27 / 7.71 ->
+    # one encoder layer before the end ("backbone" / "encN" override for experiments).
+    lat1_when = os.environ.get("TCE_LAT1_AT", f"enc{cfg.enc_layers - 2}" if cfg.enc_layers >= 2 else "backbone")
+    if ar2 is not None and stream2 is not None and lat1_when == "backbone":
+        lat1 = start_lat1()
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
     # The four levels are independent (they write disjoint slices of src).  Without the early start: level 0 on the main
     # stream, levels 1-3 as one parallel branch on the side stream (idle here: the text branch has joined, the decoder
@@ -344,6 +350,8 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             ffn(src, T * S, fp, norm=fp + "norm4")
         msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1")
         ffn(src, T * S, lp, norm=lp + "norm2")
+        if ar2 is not None and stream2 is not None and lat1_when == f"enc{i}":
+            lat1 = start_lat1()
     memory = src
 
     _stage("encoder")
