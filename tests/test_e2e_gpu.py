@@ -81,8 +81,21 @@ def test_swin_t_small_matches_reference(models):
 
 def test_swin_t_config2_fullsize_matches_reference(models):
     """BASELINE config 2: T=5, 360x640, Swin-T."""
-    fx, out, _ = _run(models, "e2e_swin_t_cfg2.npz", "swin_t_p4w7")
+    fx, out, model = _run(models, "e2e_swin_t_cfg2.npz", "swin_t_p4w7")
     _compare(out, fx, 2e-2)
+    # the same clip again: now captured and replayed as a hipGraph with all its parallel branches (text, early input
+    # projections, four lateral paths, decoder, frame-token forks) -- must reproduce the eager, single-stream result bit for
+    # bit (a missing join between branches shows up here as a mismatch or as run-to-run differences)
+    T, H, W = (int(v) for v in fx["thw"])
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    hid, pooled = torch.from_numpy(fx["text_hidden"])[0].cuda(), torch.from_numpy(fx["text_pooled"])[0].cuda()
+    n_graphs = len(model._graphs)
+    for _ in range(3):
+        again = model.forward_features(frames, hid, pooled, float(H), float(W))
+        torch.cuda.synchronize()
+        for k in ("pred_logits", "pred_boxes", "pred_masks", "memory", "reference_points"):
+            assert torch.equal(again[k], out[k]), k
+    assert len(model._graphs) == n_graphs + 1  # captured on the second sighting, replayed afterwards
 
 
 def test_resnet50_small_matches_reference(models):
