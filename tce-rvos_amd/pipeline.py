@@ -528,8 +528,11 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
                 hdn = A(ntok, hid)
                 gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
                         act=ACT_GELU)
+                # last stage: ~1200 rows against K = 3072 -- 228 workgroups walking 96 K slices each; split-K: 61 -> 41 us
+                sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
+                    if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1
                 gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
-                        ldres=C, res_mode=RES_ADD)
+                        ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
             ar.release(m0)
         if cfg.video:
             feats.append(x)
