@@ -93,6 +93,8 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     _ensure_built(local_rank, world)
+    # the pool's driver only supports dmabuf IPC: without this RCCL's buffer exchange fails (hipIpcGetMemHandle)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
