@@ -749,10 +749,21 @@ def test_single_pass_fp16_mode(ops):
             ops.ffn_fused(dev(a), fpk, dev(torch.zeros(K)), 512, ops.ACT_RELU, out=of)
             rf = a.double() + torch.relu(a.double() @ w1.double().T) @ w2.double().T
             errs[mode] += ((of.cpu().double() - rf).abs().max().item() / rf.abs().max().item(),)
+            # pixel-stationary 3x3 convolution and MFMA patch embedding follow the mode as well
+            xc, wc = torch.randn(2, 256, 12, 20, generator=g), torch.randn(256, 256, 3, 3, generator=g) / 48
+            rc = F.conv2d(xc.double(), wc.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, 256)
+            wcl = dev(wc.permute(0, 2, 3, 1).reshape(256, -1).contiguous())
+            oc = ops.conv3x3(dev(xc.permute(0, 2, 3, 1).reshape(-1, 256).contiguous()), ops.conv3x3_pack(wcl, 256), 2, 12, 20,
+                             256, 256)
+            errs[mode] += ((oc.cpu().double() - rc).abs().max().item() / rc.abs().max().item(),)
+            xp, wp = torch.randn(1, 3, 32, 48, generator=g), torch.randn(96, 3, 4, 4, generator=g) / 7
+            rp = F.layer_norm(F.conv2d(xp.double(), wp.double(), stride=4).flatten(2).transpose(1, 2), (96,)).reshape(-1, 96)
+            op_, _, _ = ops.patch_embed(dev(xp), dev(wp), dev(torch.zeros(96)), dev(torch.ones(96)), dev(torch.zeros(96)))
+            errs[mode] += ((op_.cpu().double() - rp).abs().max().item() / rp.abs().max().item(),)
     finally:
         ops.set_gemm_mode("f16x3")
-    print("errors (gemm, rowlin: relative to sum|a||b|; ffn: relative to max|out|):", errs)
-    for k in range(3):
+    print("errors (gemm, rowlin: relative to sum|a||b|; ffn, conv3x3, patch embed: relative to max|out|):", errs)
+    for k in range(5):
         assert errs["f16x3"][k] < 3e-6
         assert 1e-5 < errs["f16"][k] < 2e-3
 
