@@ -126,6 +126,16 @@ int tce_mha_f32(const float* Q, const float* K, const float* V, float* O, int32_
                 int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int64_t sQ, int64_t sK,
                 int64_t sV, int64_t sO, const uint8_t* kmask, float scale, tceStream stream);
 
+/* The same attention for LONG key sequences (the pixel decoder's self-attention over a few thousand tokens,
+ * segmentation.py:333-361) in GEMM modes 1 / 2: K and V are split to fp16 hi/lo planes once (ws, tce_mha_ws_bytes bytes,
+ * 16-byte aligned), the attention waves read their MFMA fragments straight from the planes (no LDS staging, no barrier in
+ * the key loop); with few query tiles the 4 waves of a workgroup split the keys.  Same arguments and result as
+ * tce_mha_f32 (to fp32 round-off). */
+int64_t tce_mha_ws_bytes(int32_t batch, int32_t nheads, int32_t Lk);
+int tce_mha_ws_f32(const float* Q, const float* K, const float* V, float* O, void* ws, int32_t batch, int32_t nheads,
+                   int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int64_t sQ, int64_t sK,
+                   int64_t sV, int64_t sO, const uint8_t* kmask, float scale, tceStream stream);
+
 /* Multi-scale deformable attention forward -- the drop-in for the reference's only native op
  * MultiScaleDeformableAttention_update.ms_deform_attn_forward (models/ops/src/vision.cpp:13-16,
  * ms_deform_attn_cuda.cu:21-102, ms_deform_im2col_cuda.cuh:34-85,320-455):

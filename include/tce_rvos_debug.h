@@ -19,6 +19,9 @@ int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
 int tce_debug_msda_set_lds(int32_t on);
 /* tuning aid: 1 (default) = Swin window attention on the fp32 matrix cores; 0 = the VALU kernel (A/B timing) */
 int tce_debug_window_attn_set_mfma(int32_t on);
+/* tuning aid: 1 (default) = tce_mha_f32 runs key sequences >= 256 on the fp16 matrix cores (3 x fp16 split) in GEMM
+ * modes 1 / 2; 0 = always the exact fp32-MFMA kernel (A/B timing) */
+int tce_debug_mha_set_split(int32_t on);
 #ifdef __cplusplus
 }
 #endif

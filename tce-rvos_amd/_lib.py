@@ -68,6 +68,8 @@ SIGNATURES = {
     "tce_window_attn3d_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_patch_merge_ln_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, c_f]),
     "tce_mha_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, c_f, f32, c_f]),
+    "tce_mha_ws_bytes": (i64, [i32, i32, i32]),
+    "tce_mha_ws_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, c_f, f32, c_f]),
     "tce_ms_deform_attn_forward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_ms_deform_attn_backward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_msda_fused_f32": (i32, [c_f, c_f, c_f, c_f, C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, c_f]),
@@ -111,6 +113,7 @@ DEBUG_SIGNATURES = {
     "tce_debug_ffn_set_stamp_buffer": (i32, [c_f]),
     "tce_debug_msda_set_lds": (i32, [i32]),
     "tce_debug_window_attn_set_mfma": (i32, [i32]),
+    "tce_debug_mha_set_split": (i32, [i32]),
 }
 
 _LIB = None

@@ -279,6 +279,457 @@ __global__ void __launch_bounds__(64 * NW) mha_mfma_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same attention on the fp16 matrix cores with fp32-class accuracy ("3 x fp16 split", gemm_f16x3_kernel.h):
+// the fp32 MFMA above issues at 1/16 of the fp16 rate, and the pixel decoder's self-attention over a few
+// thousand tokens (segmentation.py:333-361) spends 2048 MFMA cycles per 32-key tile on it.  Here K, V (per tile,
+// once per workgroup), Q (once) and the probabilities (per tile) are split into fp16 hi/lo and every product is three
+// v_mfma_f32_32x32x16_f16: 2 x 6 MFMAs = 384 cycles per tile.  Same transposed formulation: S^T = K Q^T has the 32
+// key scores of a query spread over the 16 accumulator registers of its two lanes, which IS the B operand of
+// O^T = V^T P^T if the k order inside a 16-key step is (j&3) + 8(j>>2) + 4*half -- V^T is written to LDS so that the
+// A operand of that order is two 8-byte reads.  Planes are rows of 32 halfs at an 80-byte pitch (conflict-free for the
+// row-per-lane 16-byte reads).  mode 2 (tce_set_gemm_mode): one MFMA per product on nearest-rounded operands.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 ah16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ah16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 afp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void attn_split2(const float a, const float b, unsigned& hi, unsigned& lo, const int single) {
+  if (single) {
+    hi = __builtin_bit_cast(unsigned, afp16x2{(__fp16)a, (__fp16)b});
+    lo = 0u;
+    return;
+  }
+  const afp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+}
+
+template <int NW, bool KSPLIT>
+__global__ void __launch_bounds__(64 * NW) mha_f16x3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, float* __restrict__ O, int nheads,
+                                                            int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
+                                                            long long sK, long long sV, long long sO,
+                                                            const uint8_t* __restrict__ kmask, float scale, const int single) {
+  // KSPLIT: the NW waves of a workgroup own the SAME 32 queries and a quarter of the keys each (private K/V tiles, no
+  // workgroup barrier inside the loop), partial (max, sum, O) merged through LDS at the end -- for long key sequences
+  // with too few query tiles to fill the chip a wave's serial chain of key tiles is what bounds the launch.
+  // otherwise: NW waves with 32 queries each share the K/V tiles.
+  constexpr int KT = 32, PITCH = 80;  // bytes per 32-half row
+  constexpr int REG = KSPLIT ? NW : 1;
+  constexpr int NLOAD = KSPLIT ? 64 : 64 * NW;  // threads that load one tile
+  __shared__ __attribute__((aligned(16))) unsigned char sKh_[REG][KT * PITCH], sKl_[REG][KT * PITCH], sVh_[REG][HD * PITCH],
+      sVl_[REG][HD * PITCH];
+  __shared__ float sM_[REG][KT];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int reg = KSPLIT ? wave : 0;
+  unsigned char* const sKh = sKh_[reg];
+  unsigned char* const sKl = sKl_[reg];
+  unsigned char* const sVh = sVh_[reg];
+  unsigned char* const sVl = sVl_[reg];
+  float* const sM = sM_[reg];
+  const int ltid = KSPLIT ? lane : tid;
+  const int bh = blockIdx.y;
+  const int b = bh / nheads, h = bh - b * nheads;
+  const int q0 = KSPLIT ? blockIdx.x * 32 : (blockIdx.x * (nthr >> 6) + wave) * 32;
+  const int qi = q0 + l31;
+  const bool qok = qi < Lq;
+  const float* Qb = Q + b * sQ + h * HD;
+  const float* Kb = K + b * sK + h * HD;
+  const float* Vb = V + b * sV + h * HD;
+  auto tile_sync = [&]() {
+    if (KSPLIT) __builtin_amdgcn_wave_barrier();  // wave-private tiles: a wave's LDS operations execute in order
+    else __syncthreads();
+  };
+  // B operand of S^T = K Q^T: lane (query, half) holds Q[q][16s + 8*half + 0..7] * scale for the two k-steps
+  typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+  ah16x8 qh[2], ql[2];
+  {
+    const float* p = Qb + (long long)min(qi, Lq - 1) * ldq;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi + 4);
+      unsigned hw[4], lw[4];
+      attn_split2(a[0] * scale, a[1] * scale, hw[0], lw[0], single);
+      attn_split2(a[2] * scale, a[3] * scale, hw[1], lw[1], single);
+      attn_split2(c[0] * scale, c[1] * scale, hw[2], lw[2], single);
+      attn_split2(c[2] * scale, c[3] * scale, hw[3], lw[3], single);
+      qh[s] = __builtin_bit_cast(ah16x8, au32x4{hw[0], hw[1], hw[2], hw[3]});
+      ql[s] = __builtin_bit_cast(ah16x8, au32x4{lw[0], lw[1], lw[2], lw[3]});
+    }
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -3.0e38f, l = 0.f;  // l is this lane-half's partial sum
+  // this wave's key range (whole tiles)
+  const int ntiles = (Lk + KT - 1) / KT;
+  const int t_begin = KSPLIT ? (int)((long long)wave * ntiles / NW) : 0;
+  const int t_end = KSPLIT ? (int)((long long)(wave + 1) * ntiles / NW) : ntiles;
+  constexpr int NLD = 256 / NLOAD;  // float4 pairs per loading thread per tile
+  f32x4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = ltid + u * NLOAD;
+      const int j = i >> 3, d4 = i & 7;
+      const int kk = min(k0 + j, Lk - 1);  // clamped: rows past the end are masked by sM
+      kreg[u] = *reinterpret_cast<const f32x4*>(Kb + (long long)kk * ldk + d4 * 4);
+      vreg[u] = *reinterpret_cast<const f32x4*>(Vb + (long long)kk * ldv + d4 * 4);
+    }
+  };
+  if (t_begin < t_end) fetch(t_begin * KT);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int k0 = t * KT;
+    const int kn = min(KT, Lk - k0);
+    tile_sync();
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = ltid + u * NLOAD;
+      const int j = i >> 3, d4 = i & 7;
+      const bool ok = j < kn;
+      f32x4 kv = kreg[u], vv = vreg[u];
+      if (!ok) kv = vv = f32x4{0.f, 0.f, 0.f, 0.f};
+      unsigned h0, l0, h1, l1;
+      attn_split2(kv[0], kv[1], h0, l0, single);
+      attn_split2(kv[2], kv[3], h1, l1, single);
+      *reinterpret_cast<au32x2*>(sKh + j * PITCH + d4 * 8) = au32x2{h0, h1};  // K[key j][4 d4 .. +3]
+      *reinterpret_cast<au32x2*>(sKl + j * PITCH + d4 * 8) = au32x2{l0, l1};
+      // V transposed: Vt[d][key j]
+      attn_split2(vv[0], vv[1], h0, l0, single);
+      attn_split2(vv[2], vv[3], h1, l1, single);
+      unsigned short* const vh = reinterpret_cast<unsigned short*>(sVh + (d4 * 4) * PITCH) + j;
+      unsigned short* const vl = reinterpret_cast<unsigned short*>(sVl + (d4 * 4) * PITCH) + j;
+      vh[0] = (unsigned short)(h0 & 0xffffu);
+      vh[PITCH / 2] = (unsigned short)(h0 >> 16);
+      vh[2 * (PITCH / 2)] = (unsigned short)(h1 & 0xffffu);
+      vh[3 * (PITCH / 2)] = (unsigned short)(h1 >> 16);
+      vl[0] = (unsigned short)(l0 & 0xffffu);
+      vl[PITCH / 2] = (unsigned short)(l0 >> 16);
+      vl[2 * (PITCH / 2)] = (unsigned short)(l1 & 0xffffu);
+      vl[3 * (PITCH / 2)] = (unsigned short)(l1 >> 16);
+    }
+    for (int j = ltid; j < KT; j += NLOAD)
+      sM[j] = (j < kn && !(kmask && kmask[(long long)b * Lk + k0 + j])) ? 0.f : -3.0e38f;
+    if (t + 1 < t_end) fetch(k0 + KT);
+    tile_sync();
+    // S^T[key][q]: A = K[key = l31][16s + 8*half + 0..7]
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const ah16x8 ah = *reinterpret_cast<const ah16x8*>(sKh + l31 * PITCH + (16 * s + 8 * lhi) * 2);
+      const ah16x8 al = *reinterpret_cast<const ah16x8*>(sKl + l31 * PITCH + (16 * s + 8 * lhi) * 2);
+      if (!single) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], st, 0, 0, 0);
+      }
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], st, 0, 0, 0);
+    }
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = fminf(st[r], 3.0e38f) + sM[crow(r, lhi)];
+      tmax = fmaxf(tmax, st[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(m, tmax);
+    const float corr = __expf(m - mnew);
+    l *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[r] *= corr;
+      const float pj = (st[r] > -1.0e38f) ? __expf(st[r] - mnew) : 0.f;
+      st[r] = pj;
+      l += pj;
+    }
+    // O^T[d][q] += V^T[d][key] P^T[key][q]; k-step s, element j <-> accumulator register 8s + j <-> key crow(8s + j, half)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) attn_split2(st[8 * s + 2 * q2], st[8 * s + 2 * q2 + 1], ph[q2], pl[q2], single);
+      const ah16x8 bh_ = __builtin_bit_cast(ah16x8, au32x4{ph[0], ph[1], ph[2], ph[3]});
+      const ah16x8 bl_ = __builtin_bit_cast(ah16x8, au32x4{pl[0], pl[1], pl[2], pl[3]});
+      // keys of elements 0..3: 16s + 4*half + 0..3; of elements 4..7: 16s + 8 + 4*half + 0..3
+      const int kb = (16 * s + 4 * lhi) * 2;
+      const au32x2 h0 = *reinterpret_cast<const au32x2*>(sVh + l31 * PITCH + kb);
+      const au32x2 h1 = *reinterpret_cast<const au32x2*>(sVh + l31 * PITCH + kb + 16);
+      const au32x2 l0 = *reinterpret_cast<const au32x2*>(sVl + l31 * PITCH + kb);
+      const au32x2 l1 = *reinterpret_cast<const au32x2*>(sVl + l31 * PITCH + kb + 16);
+      const ah16x8 vh_ = __builtin_bit_cast(ah16x8, au32x4{h0[0], h0[1], h1[0], h1[1]});
+      const ah16x8 vl_ = __builtin_bit_cast(ah16x8, au32x4{l0[0], l0[1], l1[0], l1[1]});
+      if (!single) {
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bl_, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_, bh_, o, 0, 0, 0);
+      }
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bh_, o, 0, 0, 0);
+    }
+    m = mnew;
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (KSPLIT) {
+    // merge the NW partial results of these 32 queries: O = sum_w O_w e^(m_w - m*), l likewise
+    __shared__ float sO[NW][HD][33];
+    __shared__ float sML[NW][2][32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sO[wave][crow(r, lhi)][l31] = o[r];
+    if (lhi == 0) {
+      sML[wave][0][l31] = m;
+      sML[wave][1][l31] = l;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float mstar = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mstar = fmaxf(mstar, sML[w][0][l31]);
+    float f[NW];
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      f[w] = __expf(sML[w][0][l31] - mstar);
+      l += sML[w][1][l31] * f[w];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc = fmaf(sO[w][crow(r, lhi)][l31], f[w], acc);
+      o[r] = acc;
+    }
+  }
+  if (qok) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float* po = O + b * sO + (long long)qi * ldo + h * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {  // registers 4g..4g+3 are 4 consecutive d: d = 8g + 4*lhi + (0..3)
+      f32x4 v = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(po + 8 * g4 + 4 * lhi) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long key sequences: K and V are split / transposed ONCE into fp16 planes in global memory
+//     Kh, Kl [batch*heads][Lkp][32]   (row = key, 64 bytes)        Vh, Vl [batch*heads][Lkp/32][32 channels][32 keys]
+// (Lkp = Lk rounded up to 32, padding zero) and the attention waves read their MFMA A fragments of a key tile
+// straight from those planes: no LDS staging, no per-tile conversion, no barrier inside the key loop -- the staged
+// kernel above re-splits every K/V tile in every workgroup, which is what its time goes to once the MFMAs are cheap.
+// KSPLIT as above (4 waves = 4 key ranges of the same 32 queries, merged through LDS at the end).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mha_planes_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                         unsigned char* __restrict__ ws, int nheads, int Lk, int Lkp, int ldk,
+                                                         int ldv, long long sK, long long sV, long long plane, int single) {
+  // one workgroup = one 32-key tile of one (batch, head); thread (j = key, d4 = 4 channels)
+  __shared__ unsigned short tvh[32][36], tvl[32][36];  // [d][key] with a padded pitch
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / nheads, h = bh - b * nheads;
+  const int k0 = blockIdx.x * 32;
+  const int j = tid >> 3, d4 = tid & 7;
+  const int key = k0 + j;
+  f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+  if (key < Lk) {
+    kv = *reinterpret_cast<const f32x4*>(K + b * sK + (long long)key * ldk + h * HD + d4 * 4);
+    vv = *reinterpret_cast<const f32x4*>(V + b * sV + (long long)key * ldv + h * HD + d4 * 4);
+  }
+  typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+  unsigned h0, l0, h1, l1;
+  attn_split2(kv[0], kv[1], h0, l0, single);
+  attn_split2(kv[2], kv[3], h1, l1, single);
+  unsigned char* const Kh = ws + (long long)bh * Lkp * 64;
+  unsigned char* const Kl = Kh + plane;
+  *reinterpret_cast<au32x2*>(Kh + (long long)key * 64 + d4 * 8) = au32x2{h0, h1};
+  *reinterpret_cast<au32x2*>(Kl + (long long)key * 64 + d4 * 8) = au32x2{l0, l1};
+  attn_split2(vv[0], vv[1], h0, l0, single);
+  attn_split2(vv[2], vv[3], h1, l1, single);
+  tvh[4 * d4 + 0][j] = (unsigned short)(h0 & 0xffffu);
+  tvh[4 * d4 + 1][j] = (unsigned short)(h0 >> 16);
+  tvh[4 * d4 + 2][j] = (unsigned short)(h1 & 0xffffu);
+  tvh[4 * d4 + 3][j] = (unsigned short)(h1 >> 16);
+  tvl[4 * d4 + 0][j] = (unsigned short)(l0 & 0xffffu);
+  tvl[4 * d4 + 1][j] = (unsigned short)(l0 >> 16);
+  tvl[4 * d4 + 2][j] = (unsigned short)(l1 & 0xffffu);
+  tvl[4 * d4 + 3][j] = (unsigned short)(l1 >> 16);
+  __syncthreads();
+  // thread (d = tid >> 3, k4 = tid & 7): 4 consecutive keys of channel d -> 8 bytes
+  const int d = tid >> 3, k4 = tid & 7;
+  // V^T tile by tile: [tile][channel d][32 keys], so that a key tile is 2 KiB of contiguous rows like K's
+  unsigned char* const Vh = ws + 2 * plane + ((long long)bh * (Lkp / 32) + blockIdx.x) * 2048;
+  unsigned char* const Vl = Vh + plane;
+  const unsigned short* rh = &tvh[d][4 * k4];
+  const unsigned short* rl = &tvl[d][4 * k4];
+  *reinterpret_cast<au32x2*>(Vh + d * 64 + 8 * k4) =
+      au32x2{(unsigned)rh[0] | ((unsigned)rh[1] << 16), (unsigned)rh[2] | ((unsigned)rh[3] << 16)};
+  *reinterpret_cast<au32x2*>(Vl + d * 64 + 8 * k4) =
+      au32x2{(unsigned)rl[0] | ((unsigned)rl[1] << 16), (unsigned)rl[2] | ((unsigned)rl[3] << 16)};
+}
+
+template <bool KSPLIT>
+__global__ void __launch_bounds__(256) mha_presplit_kernel(const float* __restrict__ Q, const unsigned char* __restrict__ ws,
+                                                           float* __restrict__ O, int nheads, int Lq, int Lk, int Lkp, int ldq,
+                                                           int ldo, long long sQ, long long sO, long long plane,
+                                                           const uint8_t* __restrict__ kmask, float scale, const int single) {
+  constexpr int KT = 32, NW = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / nheads, h = bh - b * nheads;
+  const int q0 = KSPLIT ? blockIdx.x * 32 : (blockIdx.x * NW + wave) * 32;
+  const int qi = q0 + l31;
+  const bool qok = qi < Lq;
+  const float* Qb = Q + b * sQ + h * HD;
+  const unsigned char* const Kh = ws + (long long)bh * Lkp * 64;
+  const unsigned char* const Kl = Kh + plane;
+  const unsigned char* const Vh = ws + 2 * plane + (long long)bh * (Lkp / 32) * 2048;
+  const unsigned char* const Vl = Vh + plane;
+  typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+  ah16x8 qh[2], ql[2];
+  {
+    const float* p = Qb + (long long)min(qi, Lq - 1) * ldq;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi + 4);
+      unsigned hw[4], lw[4];
+      attn_split2(a[0] * scale, a[1] * scale, hw[0], lw[0], single);
+      attn_split2(a[2] * scale, a[3] * scale, hw[1], lw[1], single);
+      attn_split2(c[0] * scale, c[1] * scale, hw[2], lw[2], single);
+      attn_split2(c[2] * scale, c[3] * scale, hw[3], lw[3], single);
+      qh[s] = __builtin_bit_cast(ah16x8, au32x4{hw[0], hw[1], hw[2], hw[3]});
+      ql[s] = __builtin_bit_cast(ah16x8, au32x4{lw[0], lw[1], lw[2], lw[3]});
+    }
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -3.0e38f, l = 0.f;
+  const int ntiles = Lkp / KT;
+  const int t_begin = KSPLIT ? (int)((long long)wave * ntiles / NW) : 0;
+  const int t_end = KSPLIT ? (int)((long long)(wave + 1) * ntiles / NW) : ntiles;
+  // fragments of one key tile: K (hi, lo) x 2 k-steps, V^T (hi, lo) x 2 k-steps x 2 runs of 4 keys
+  struct Frag {
+    ah16x8 kh[2], kl[2];
+    au32x2 vh[2][2], vl[2][2];
+  };
+  auto load_tile = [&](Frag& f, const int t) {
+    const long long krow = ((long long)t * KT + l31) * 64;
+    const long long vrow = (long long)t * 2048 + l31 * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f.kh[s] = *reinterpret_cast<const ah16x8*>(Kh + krow + (16 * s + 8 * lhi) * 2);
+      f.kl[s] = *reinterpret_cast<const ah16x8*>(Kl + krow + (16 * s + 8 * lhi) * 2);
+      const int kb = (16 * s + 4 * lhi) * 2;
+      f.vh[s][0] = *reinterpret_cast<const au32x2*>(Vh + vrow + kb);
+      f.vh[s][1] = *reinterpret_cast<const au32x2*>(Vh + vrow + kb + 16);
+      f.vl[s][0] = *reinterpret_cast<const au32x2*>(Vl + vrow + kb);
+      f.vl[s][1] = *reinterpret_cast<const au32x2*>(Vl + vrow + kb + 16);
+    }
+  };
+  Frag cur, nxt;
+  if (t_begin < t_end) load_tile(cur, t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) load_tile(nxt, t + 1);
+    const int k0 = t * KT;
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (!single) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.kh[s], ql[s], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.kl[s], qh[s], st, 0, 0, 0);
+      }
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.kh[s], qh[s], st, 0, 0, 0);
+    }
+    float tmax = -3.0e38f;
+    const bool edge = k0 + KT > Lk || kmask != nullptr;  // uniform
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = fminf(st[r], 3.0e38f);
+      if (edge) {
+        const int key = k0 + crow(r, lhi);
+        if (key >= Lk || (kmask && kmask[(long long)b * Lk + key])) v = -3.0e38f;
+      }
+      st[r] = v;
+      tmax = fmaxf(tmax, v);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(m, tmax);
+    const float corr = __expf(m - mnew);
+    l *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[r] *= corr;
+      const float pj = (st[r] > -1.0e38f) ? __expf(st[r] - mnew) : 0.f;
+      st[r] = pj;
+      l += pj;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) attn_split2(st[8 * s + 2 * q2], st[8 * s + 2 * q2 + 1], ph[q2], pl[q2], single);
+      const ah16x8 bh_ = __builtin_bit_cast(ah16x8, au32x4{ph[0], ph[1], ph[2], ph[3]});
+      const ah16x8 bl_ = __builtin_bit_cast(ah16x8, au32x4{pl[0], pl[1], pl[2], pl[3]});
+      const ah16x8 vh_ = __builtin_bit_cast(ah16x8, au32x4{cur.vh[s][0][0], cur.vh[s][0][1], cur.vh[s][1][0], cur.vh[s][1][1]});
+      const ah16x8 vl_ = __builtin_bit_cast(ah16x8, au32x4{cur.vl[s][0][0], cur.vl[s][0][1], cur.vl[s][1][0], cur.vl[s][1][1]});
+      if (!single) {
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bl_, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_, bh_, o, 0, 0, 0);
+      }
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bh_, o, 0, 0, 0);
+    }
+    m = mnew;
+    cur = nxt;
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (KSPLIT) {
+    __shared__ float sO[NW][HD][33];
+    __shared__ float sML[NW][2][32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sO[wave][crow(r, lhi)][l31] = o[r];
+    if (lhi == 0) {
+      sML[wave][0][l31] = m;
+      sML[wave][1][l31] = l;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float mstar = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mstar = fmaxf(mstar, sML[w][0][l31]);
+    float f[NW];
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      f[w] = __expf(sML[w][0][l31] - mstar);
+      l += sML[w][1][l31] * f[w];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc = fmaf(sO[w][crow(r, lhi)][l31], f[w], acc);
+      o[r] = acc;
+    }
+  }
+  if (qok) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float* po = O + b * sO + (long long)qi * ldo + h * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 v = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(po + 8 * g4 + 4 * lhi) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Swin window attention on the matrix cores (exact fp32 MFMA, v_mfma_f32_32x32x2_f32), same index arithmetic as
 // window_attn_kernel above.  A workgroup = 4 waves = two (frame, window, head) items; the two waves of an item own
 // the query tiles 0..31 and 32..48 of the window and share its K / V (49 keys, zero-padded to 64) in LDS.  As in
@@ -614,6 +1065,13 @@ extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, cons
   return TCE_OK;
 }
 
+// A/B switch (include/tce_rvos_debug.h): 0 keeps every attention launch on the exact fp32-MFMA kernel
+static int g_mha_split = 1;
+extern "C" int tce_debug_mha_set_split(int32_t on) {
+  g_mha_split = on;
+  return TCE_OK;
+}
+
 extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float* O, int32_t batch, int32_t nheads,
                            int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int64_t sQ,
                            int64_t sK, int64_t sV, int64_t sO, const uint8_t* kmask, float scale, tceStream stream) {
@@ -628,6 +1086,26 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
   const long long tiles = (long long)tce_cdiv(Lq, 32) * batch * nheads;
   const int nw = (tiles >= 4096) ? 4 : 1;
   dim3 grid(tce_cdiv(Lq, 32 * nw), batch * nheads);
+  // split-fp16 / fp16 modes: long key sequences on the fp16 matrix cores (5x fewer MFMA cycles per key tile); short ones
+  // (text keys, frame tokens) are launch-bound either way and stay on the exact kernel, as does mode 0
+  if (g_mha_split && tce_get_gemm_mode() != 0 && Lk >= 256) {
+    const int single = tce_gemm_single_pass();
+    // few query tiles against many keys: split the keys over the 4 waves of a workgroup (4x shorter serial chains)
+    const bool ksplit = tiles < 4096 && Lk >= 1024;
+    if (ksplit) {
+      dim3 gk(tce_cdiv(Lq, 32), batch * nheads);
+      hipLaunchKernelGGL((mha_f16x3_kernel<4, true>), gk, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
+                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+    } else if (nw == 4) {
+      hipLaunchKernelGGL((mha_f16x3_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
+                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+    } else {
+      hipLaunchKernelGGL((mha_f16x3_kernel<1, false>), grid, dim3(64), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
+                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+    }
+    TCE_CHECK_LAUNCH("tce_mha_f32");
+    return TCE_OK;
+  }
   if (nw == 4)
     hipLaunchKernelGGL(mha_mfma_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
                        ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
@@ -635,6 +1113,43 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
     hipLaunchKernelGGL(mha_mfma_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq, ldk,
                        ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
   TCE_CHECK_LAUNCH("tce_mha_f32");
+  return TCE_OK;
+}
+
+extern "C" int64_t tce_mha_ws_bytes(int32_t batch, int32_t nheads, int32_t Lk) {
+  const long long Lkp = (Lk + 31) / 32 * 32;
+  return 4 * (long long)batch * nheads * Lkp * 64;
+}
+
+extern "C" int tce_mha_ws_f32(const float* Q, const float* K, const float* V, float* O, void* ws, int32_t batch,
+                              int32_t nheads, int32_t Lq, int32_t Lk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                              int64_t sQ, int64_t sK, int64_t sV, int64_t sO, const uint8_t* kmask, float scale,
+                              tceStream stream) {
+  TCE_CHECK_ARG(Q && K && V && O && ws, "tce_mha_ws_f32: null pointer");
+  TCE_CHECK_ARG(batch > 0 && nheads > 0 && Lq > 0 && Lk > 0, "tce_mha_ws_f32: bad sizes");
+  TCE_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && sQ % 4 == 0 && sK % 4 == 0 &&
+                    sV % 4 == 0 && sO % 4 == 0,
+                "tce_mha_ws_f32: leading dims / strides must be multiples of 4");
+  TCE_CHECK_ARG(tce_aligned16(Q) && tce_aligned16(K) && tce_aligned16(V) && tce_aligned16(O) && tce_aligned16(ws),
+                "tce_mha_ws_f32: pointers must be 16-byte aligned");
+  TCE_CHECK_ARG(tce_get_gemm_mode() != 0, "tce_mha_ws_f32: split-fp16 arithmetic; in exact-fp32 mode use tce_mha_f32");
+  const int Lkp = (Lk + 31) / 32 * 32;
+  const long long plane = (long long)batch * nheads * Lkp * 64;
+  const int single = tce_gemm_single_pass();
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mha_planes_kernel, dim3(Lkp / 32, batch * nheads), dim3(256), 0, s, K, V, (unsigned char*)ws, nheads, Lk,
+                     Lkp, ldk, ldv, (long long)sK, (long long)sV, plane, single);
+  const long long tiles = (long long)tce_cdiv(Lq, 32) * batch * nheads;
+  if (tiles < 4096) {  // too few query tiles to fill the chip: the 4 waves of a workgroup split the keys
+    hipLaunchKernelGGL((mha_presplit_kernel<true>), dim3(tce_cdiv(Lq, 32), batch * nheads), dim3(256), 0, s, Q,
+                       (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
+                       scale, single);
+  } else {
+    hipLaunchKernelGGL((mha_presplit_kernel<false>), dim3(tce_cdiv(Lq, 128), batch * nheads), dim3(256), 0, s, Q,
+                       (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
+                       scale, single);
+  }
+  TCE_CHECK_LAUNCH("tce_mha_ws_f32");
   return TCE_OK;
 }
 

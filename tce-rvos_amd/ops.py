@@ -349,11 +349,25 @@ def patch_merge_ln(x, gamma, beta, T, H, W, Cn, eps=1e-5, out=None, alloc=None):
     return out, H2, W2
 
 
-def mha_core(q, k, v, batch, nheads, Lq, Lk, ldq, ldk, ldv, sQ, sK, sV, out, ldo, sO, kmask=None, scale=None):
+if os.environ.get("TCE_MHA_SPLIT", "1") == "0":  # A/B: every attention launch on the exact fp32-MFMA kernel
+    lib().tce_debug_mha_set_split(0)
+
+
+MHA_WS_MIN_KEYS = int(os.environ.get("TCE_MHA_WS_MIN_KEYS", 1024))
+
+
+def mha_core(q, k, v, batch, nheads, Lq, Lk, ldq, ldk, ldv, sQ, sK, sV, out, ldo, sO, kmask=None, scale=None, alloc=None):
     """Raw-strided attention core; q/k/v/out are tensors whose data_ptr() is the first element of
-    (batch 0, row 0, head 0).  Strides in floats."""
+    (batch 0, row 0, head 0).  Strides in floats.  alloc: long key sequences take the pre-split form (tce_mha_ws_f32),
+    whose fp16 planes of K / V come from it."""
     if scale is None:
         scale = 32 ** -0.5
+    if alloc is not None and Lk >= MHA_WS_MIN_KEYS and get_gemm_mode() != "f32":
+        ws = alloc(lib().tce_mha_ws_bytes(batch, nheads, Lk) // 4)
+        check(lib().tce_mha_ws_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), batch, nheads, Lq, Lk,
+                                   ldq, ldk, ldv, ldo, sQ, sK, sV, sO, kmask.data_ptr() if kmask is not None else None, scale,
+                                   _stream()), "tce_mha_ws_f32")
+        return out
     check(lib().tce_mha_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, nheads, Lq, Lk, ldq, ldk,
                             ldv, ldo, sQ, sK, sV, sO, kmask.data_ptr() if kmask is not None else None, scale,
                             _stream()), "tce_mha_f32")

@@ -631,7 +631,7 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                 lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
         v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
         att = A(n_low, D)
-        ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+        ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
         o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
         ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
     else:
@@ -641,7 +641,7 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                 batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
         v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
         att = A(n, D)
-        ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+        ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
         gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                 ldres=D, res_mode=RES_ADD)
     arx.release(m1)

@@ -219,7 +219,11 @@ def test_patch_merge_ln(ops, T, H, W, C):
 
 
 @pytest.mark.parametrize("batch,nh,Lq,Lk,masked", [(1, 8, 1200, 1200, False), (5, 8, 700, 8, False), (1, 8, 40, 40, False),
-                                                    (5, 2, 5, 5, False), (1, 8, 300, 32, True), (2, 4, 65, 33, True)])
+                                                    (5, 2, 5, 5, False), (1, 8, 300, 32, True), (2, 4, 65, 33, True),
+                                                    # Lk >= 256: the split-fp16 kernel (one wave / four waves per workgroup)
+                                                    (1, 8, 2300, 2300, False), (5, 8, 3600, 301, True), (2, 3, 77, 257, True),
+                                                    # few query tiles, >= 1024 keys: keys split over the waves of a workgroup
+                                                    (1, 8, 4600, 4600, False), (2, 4, 100, 1101, True), (1, 2, 33, 1024, False)])
 def test_mha_core(ops, batch, nh, Lq, Lk, masked):
     g = torch.Generator().manual_seed(Lq + Lk)
     E = nh * 32
@@ -238,6 +242,24 @@ def test_mha_core(ops, batch, nh, Lq, Lk, masked):
     ops.mha_core(dev(q), dev(k), dev(v), batch, nh, Lq, Lk, E, E, E, Lq * E, Lk * E, Lk * E, out, E, Lq * E,
                  kmask=dev(km.to(torch.uint8)) if masked else None)
     close(out, ref, 1e-4, 1e-5)
+    if Lk >= 256:  # exact-fp32 mode runs the fp32-MFMA kernel: both must agree to fp32 round-off
+        exact = torch.empty_like(out)
+        try:
+            ops.set_gemm_mode("f32")
+            ops.mha_core(dev(q), dev(k), dev(v), batch, nh, Lq, Lk, E, E, E, Lq * E, Lk * E, Lk * E, exact, E, Lq * E,
+                         kmask=dev(km.to(torch.uint8)) if masked else None)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_gemm_mode("f16x3")
+        close(exact, ref, 1e-4, 1e-5)
+        assert (exact - out).abs().max().item() < 5e-6
+    if Lk >= 1024:  # pre-split form (tce_mha_ws_f32): K / V planes from a caller-provided workspace
+        ws_out = torch.empty_like(out)
+        ops.mha_core(dev(q), dev(k), dev(v), batch, nh, Lq, Lk, E, E, E, Lq * E, Lk * E, Lk * E, ws_out, E, Lq * E,
+                     kmask=dev(km.to(torch.uint8)) if masked else None,
+                     alloc=lambda n: torch.empty(n, dtype=torch.float32, device="cuda"))
+        close(ws_out, ref, 1e-4, 1e-5)
+        assert (ws_out - out).abs().max().item() < 5e-6
 
 
 def test_msda_reference_op_matches_reference_fixture(ops):
