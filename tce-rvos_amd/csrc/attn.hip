@@ -1036,6 +1036,204 @@ __global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same 3-D window attention on the fp16 matrix cores, fp32-class accuracy through the
+// 3 x fp16 split of mha_f16x3_kernel above (mode 2: one MFMA per product).  A workgroup = one (window, head), NW waves.
+// The window's K and V^T (<= 392 keys, zero-padded to a multiple of 32) are split to fp16 hi/lo planes ONCE and stay in
+// LDS (K rows at an 80-byte pitch, V^T rows at NKP*2 + 8 bytes: both conflict-free for the fragment reads); the waves
+// walk the query tiles (32 queries each) against all key tiles.  Scores are computed transposed (S^T = K Q^T: a lane
+// owns ONE query and 16 keys of the tile in its accumulator registers), so the relative-position bias -- table index
+// = code(i) - code(j) + const with code(n) = the token's full-window coordinates folded to (d*13 + y)*13 + x, the
+// [:N,:N] slicing quirk included -- and the -100 region mask are added in registers, the online softmax is in-register
+// + one cross-half shuffle, and P^T is the B operand of O^T = V^T P^T without leaving the registers.
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float* __restrict__ qkv,
+                                                                     const float* __restrict__ qkv_bias,
+                                                                     const float* __restrict__ table,
+                                                                     float* __restrict__ out, Win3D g, int C, int nH,
+                                                                     int table_rows, int NKP, const int single) {
+  typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3m[];
+  constexpr int KPITCH = 80;
+  const int VPITCH = NKP * 2 + 8;
+  const int N = g.wd * g.wh * g.ww;
+  unsigned char* const sKh = smem3m;
+  unsigned char* const sKl = sKh + NKP * KPITCH;
+  unsigned char* const sVh = sKl + NKP * KPITCH;
+  unsigned char* const sVl = sVh + HD * VPITCH;
+  float* const sB = reinterpret_cast<float*>(sVl + HD * VPITCH);
+  int* const sSrc = reinterpret_cast<int*>(sB + ((table_rows + 3) & ~3));  // [NKP] source token row, -1 padded token, -2 no token
+  int* const sCR = sSrc + NKP;                                            // [NKP] code | region id << 16
+  const int tid = threadIdx.x, nthr = 64 * NW;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int h = blockIdx.x % nH;
+  int widx = blockIdx.x / nH;
+  const int nwx = g.Wp / g.ww, nwy = g.Hp / g.wh;
+  const int bx = widx % nwx; widx /= nwx;
+  const int by = widx % nwy;
+  const int bd = widx / nwy;
+  const int C3 = 3 * C;
+  const int fhw = g.fh * g.fw;
+  for (int n = tid; n < NKP; n += nthr) {
+    int src = -2, cr = 0;
+    if (n < N) {
+      const int x = n % g.ww, y = (n / g.ww) % g.wh, d = n / (g.ww * g.wh);
+      const int dd = bd * g.wd + d, yy = by * g.wh + y, xx = bx * g.ww + x;  // shifted-grid coordinates
+      int ds = dd + g.sd, ys = yy + g.sh, xs = xx + g.sw;
+      if (ds >= g.Dp) ds -= g.Dp;
+      if (ys >= g.Hp) ys -= g.Hp;
+      if (xs >= g.Wp) xs -= g.Wp;
+      src = (ds < g.D && ys < g.H && xs < g.W) ? (ds * g.H + ys) * g.W + xs : -1;
+      const int rd = g.sd > 0 ? (dd < g.Dp - g.wd ? 0 : (dd < g.Dp - g.sd ? 1 : 2)) : 0;
+      const int ry = g.sh > 0 ? (yy < g.Hp - g.wh ? 0 : (yy < g.Hp - g.sh ? 1 : 2)) : 0;
+      const int rx = g.sw > 0 ? (xx < g.Wp - g.ww ? 0 : (xx < g.Wp - g.sw ? 1 : 2)) : 0;
+      // full-window coordinates of flat index n (relative_position_index[:N,:N] of the nominal window)
+      const int code = ((n / fhw) * (2 * g.fh - 1) + (n % fhw) / g.fw) * (2 * g.fw - 1) + n % g.fw;
+      cr = code | (((rd * 3 + ry) * 3 + rx) << 16);
+    }
+    sSrc[n] = src;
+    sCR[n] = cr;
+  }
+  for (int i = tid; i < table_rows; i += nthr) sB[i] = table[(long long)i * nH + h];
+  __syncthreads();
+  // K -> [key][32 halfs] hi / lo planes, V -> transposed [d][key] hi / lo planes; rows past N are zero
+  for (int i = tid; i < NKP * 8; i += nthr) {
+    const int n = i >> 3, d4 = i & 7;
+    const int srow = sSrc[n];
+    f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+    if (srow >= 0) {
+      const float* p = qkv + (long long)srow * C3 + h * HD + d4 * 4;
+      kv = *reinterpret_cast<const f32x4*>(p + C);
+      vv = *reinterpret_cast<const f32x4*>(p + 2 * C);
+    } else if (srow == -1) {
+      kv = *reinterpret_cast<const f32x4*>(qkv_bias + C + h * HD + d4 * 4);
+      vv = *reinterpret_cast<const f32x4*>(qkv_bias + 2 * C + h * HD + d4 * 4);
+    }
+    unsigned h0, l0, h1, l1;
+    attn_split2(kv[0], kv[1], h0, l0, single);
+    attn_split2(kv[2], kv[3], h1, l1, single);
+    *reinterpret_cast<au32x2*>(sKh + n * KPITCH + d4 * 8) = au32x2{h0, h1};
+    *reinterpret_cast<au32x2*>(sKl + n * KPITCH + d4 * 8) = au32x2{l0, l1};
+    attn_split2(vv[0], vv[1], h0, l0, single);
+    attn_split2(vv[2], vv[3], h1, l1, single);
+    unsigned short* const vh = reinterpret_cast<unsigned short*>(sVh + (d4 * 4) * VPITCH) + n;
+    unsigned short* const vl = reinterpret_cast<unsigned short*>(sVl + (d4 * 4) * VPITCH) + n;
+    const int vp = VPITCH / 2;
+    vh[0] = (unsigned short)(h0 & 0xffffu);
+    vh[vp] = (unsigned short)(h0 >> 16);
+    vh[2 * vp] = (unsigned short)(h1 & 0xffffu);
+    vh[3 * vp] = (unsigned short)(h1 >> 16);
+    vl[0] = (unsigned short)(l0 & 0xffffu);
+    vl[vp] = (unsigned short)(l0 >> 16);
+    vl[2 * vp] = (unsigned short)(l1 & 0xffffu);
+    vl[3 * vp] = (unsigned short)(l1 >> 16);
+  }
+  __syncthreads();
+  const bool masked = (g.sd | g.sh | g.sw) != 0;
+  const float scale = 0.17677669529663687f;
+  const int koff = ((g.fd - 1) * (2 * g.fh - 1) + (g.fh - 1)) * (2 * g.fw - 1) + (g.fw - 1);
+  const int nkt = NKP / 32, nqt = (N + 31) / 32;
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int qi = qt * 32 + l31;
+    const int qc = min(qi, N - 1);
+    const int srow = sSrc[qc];
+    const int crq = sCR[qc];
+    const int ci = (crq & 0xffff) + koff, rid = crq >> 16;
+    ah16x8 qh[2], ql[2];
+    {
+      const float* p = srow >= 0 ? qkv + (long long)srow * C3 + h * HD : qkv_bias + h * HD;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + 16 * s + 8 * lhi + 4);
+        unsigned hw[4], lw[4];
+        attn_split2(a[0] * scale, a[1] * scale, hw[0], lw[0], single);
+        attn_split2(a[2] * scale, a[3] * scale, hw[1], lw[1], single);
+        attn_split2(c[0] * scale, c[1] * scale, hw[2], lw[2], single);
+        attn_split2(c[2] * scale, c[3] * scale, hw[3], lw[3], single);
+        qh[s] = __builtin_bit_cast(ah16x8, au32x4{hw[0], hw[1], hw[2], hw[3]});
+        ql[s] = __builtin_bit_cast(ah16x8, au32x4{lw[0], lw[1], lw[2], lw[3]});
+      }
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int k0 = kt * 32;
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const ah16x8 ah = *reinterpret_cast<const ah16x8*>(sKh + (k0 + l31) * KPITCH + (16 * s + 8 * lhi) * 2);
+        const ah16x8 al = *reinterpret_cast<const ah16x8*>(sKl + (k0 + l31) * KPITCH + (16 * s + 8 * lhi) * 2);
+        if (!single) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], st, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], st, 0, 0, 0);
+        }
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], st, 0, 0, 0);
+      }
+      float tmax = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = k0 + crow(r, lhi);
+        const int cr = sCR[j];
+        float a = st[r] + sB[ci - (cr & 0xffff)];
+        if (masked && (cr >> 16) != rid) a += -100.0f;
+        if (j >= N) a = -3.0e38f;
+        st[r] = a;
+        tmax = fmaxf(tmax, a);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m, tmax);
+      const float corr = __expf(m - mnew);
+      l *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[r] *= corr;
+        const float pj = (st[r] > -1.0e38f) ? __expf(st[r] - mnew) : 0.f;
+        st[r] = pj;
+        l += pj;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) attn_split2(st[8 * s + 2 * q2], st[8 * s + 2 * q2 + 1], ph[q2], pl[q2], single);
+        const ah16x8 bh_ = __builtin_bit_cast(ah16x8, au32x4{ph[0], ph[1], ph[2], ph[3]});
+        const ah16x8 bl_ = __builtin_bit_cast(ah16x8, au32x4{pl[0], pl[1], pl[2], pl[3]});
+        const int kb = (k0 + 16 * s + 4 * lhi) * 2;
+        const au32x2 h0 = *reinterpret_cast<const au32x2*>(sVh + l31 * VPITCH + kb);
+        const au32x2 h1 = *reinterpret_cast<const au32x2*>(sVh + l31 * VPITCH + kb + 16);
+        const au32x2 l0 = *reinterpret_cast<const au32x2*>(sVl + l31 * VPITCH + kb);
+        const au32x2 l1 = *reinterpret_cast<const au32x2*>(sVl + l31 * VPITCH + kb + 16);
+        const ah16x8 vh_ = __builtin_bit_cast(ah16x8, au32x4{h0[0], h0[1], h1[0], h1[1]});
+        const ah16x8 vl_ = __builtin_bit_cast(ah16x8, au32x4{l0[0], l0[1], l1[0], l1[1]});
+        if (!single) {
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bl_, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_, bh_, o, 0, 0, 0);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bh_, o, 0, 0, 0);
+      }
+      m = mnew;
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qi < N && srow >= 0) {
+      const float inv = 1.0f / l;
+      float* po = out + (long long)srow * C + h * HD;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+        *reinterpret_cast<f32x4*>(po + 8 * g4 + 4 * lhi) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int g_window_attn_mfma = 1;  // tuning aid (tce_debug_window_attn_set_mfma): 0 = the VALU kernel
@@ -1183,6 +1381,25 @@ extern "C" int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn3d_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
+  }
+  if (g_window_attn_mfma && tce_get_gemm_mode() != 0) {
+    // fp16 matrix cores (3 x fp16 split; mode 2: single pass).  8 waves per workgroup: two per SIMD, so one wave's softmax
+    // (VALU) runs under the other's MFMAs; the 13 query tiles of a full window take two rounds.
+    constexpr int NW = 8;
+    const int NKP = (N + 31) / 32 * 32;
+    const size_t smem_m = (size_t)2 * NKP * 80 + (size_t)2 * 32 * (NKP * 2 + 8) + (size_t)((table_rows + 3) & ~3) * 4 +
+                          (size_t)2 * NKP * 4;
+    static bool attr_set_m = false;
+    if (!attr_set_m) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn3d_mfma_kernel<NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set_m = true;
+    }
+    TCE_CHECK_ARG(smem_m <= 160 * 1024, "tce_window_attn3d_f32: window does not fit the LDS");
+    hipLaunchKernelGGL(window_attn3d_mfma_kernel<NW>, dim3(nwin * nH), dim3(64 * NW), smem_m, (hipStream_t)stream, qkv,
+                       qkv_bias, bias_table, out, g, C, nH, table_rows, NKP, tce_gemm_single_pass());
+    TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
+    return TCE_OK;
   }
   hipLaunchKernelGGL(window_attn3d_kernel, dim3(nwin * nH), dim3(256), smem, (hipStream_t)stream, qkv, qkv_bias,
                      bias_table, out, g, C, nH, table_rows);

@@ -12,14 +12,34 @@ void tce_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static int* g_range_flag = nullptr;
-int* tce_range_flag() { return g_range_flag; }
+// One range flag per device: a kernel launched on device B must never store to device A's flag.  The
+// launch wrappers look the flag up from the calling thread's current device; registration files the pointer under
+// the device that owns it (NULL: disables the check on the current device).
+#define TCE_MAX_DEVICES 64
+static int* g_range_flag[TCE_MAX_DEVICES] = {nullptr};
+int* tce_range_flag() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TCE_MAX_DEVICES) return nullptr;
+  return g_range_flag[dev];
+}
 extern "C" int tce_set_range_flag(int32_t* flag) {
-  g_range_flag = flag;
+  int dev = 0;
+  if (flag != nullptr) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, flag);
+    TCE_CHECK_ARG(e == hipSuccess && at.type == hipMemoryTypeDevice, "tce_set_range_flag: flag must be device memory");
+    dev = at.device;
+  } else {
+    (void)hipGetDevice(&dev);
+  }
+  TCE_CHECK_ARG(dev >= 0 && dev < TCE_MAX_DEVICES, "tce_set_range_flag: device index out of range");
+  g_range_flag[dev] = flag;
   return TCE_OK;
 }
 
-extern "C" int tce_abi_version(void) { return 1; }
+// 2: round 2 changed tce_embed_ln_f32 / the GroupNorm workspace size and dropped three round-1 entries
+// 3: per-device range flag, window_attn3d on the matrix cores, per-site arithmetic (round 3)
+extern "C" int tce_abi_version(void) { return 3; }
 extern "C" const char* tce_last_error(void) { return g_err; }
 
 extern "C" int tce_graph_begin(tceStream stream) {

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
         v[j] = (chunk >= 0 && chunk < NC) ? W2[(long long)(32 * t + r) * Hd + k] : 0.f;
       }
     }
-    const HL f = split8(v);
+    const HL f = split8(v, single);
     o = __builtin_bit_cast(u32x4, plane ? f.lo : f.hi);
   }
   reinterpret_cast<u32x4*>(out)[u] = o;

@@ -82,6 +82,28 @@ def get_gemm_mode():
     return {0: "f32", 1: "f16x3", 2: "f16"}[lib().tce_get_gemm_mode()]
 
 
+class arith:
+    """`with ops.arith("f16"):` -- the launches (and weight packs) inside run in that arithmetic; None = leave the
+    process mode alone.  The mode is read on the host when a launch is issued (it is an argument of the kernels), so
+    a captured hipGraph keeps, per node, the mode that was current at capture: this is how one clip mixes single-pass
+    fp16 sites with split-fp16 ones (model.arith_policy, BASELINE config 5)."""
+
+    def __init__(self, mode):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        if self.mode is not None:
+            self.prev = get_gemm_mode()
+            if self.prev != self.mode:
+                set_gemm_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode is not None and self.prev != self.mode:
+            set_gemm_mode(self.prev)
+        return False
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -104,12 +126,15 @@ class RangeError(RuntimeError):
 def range_flag(device=None):
     """The device flag (int32[1]) registered with the library; created (and registered) on first use."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     st = _RANGE.get(dev)
     if st is None:
         st = {"flag": torch.zeros(1, dtype=torch.int32, device=dev), "host": torch.zeros(1, dtype=torch.int32).pin_memory(),
               "event": None}
         _RANGE[dev] = st
-    check(lib().tce_set_range_flag(st["flag"].data_ptr()), "tce_set_range_flag")
+        # the library keeps one flag per device (filed under the device that owns the pointer): registered once
+        check(lib().tce_set_range_flag(st["flag"].data_ptr()), "tce_set_range_flag")
     return st
 
 
@@ -239,7 +264,7 @@ def conv2d_cl(x, w_packed, T, H, W, Cin, kh, kw, stride, pad, bias=None, act=ACT
     M = T * Ho * Wo
     if (kh == 3 and kw == 3 and stride == 1 and pad == 1 and act == ACT_NONE and res_mode == RES_NONE and splitk == 1
             and M >= CONV3_MIN_PIXELS and get_gemm_mode() != "f32"):
-        pk = CONV3_TABLE.get((w_packed.data_ptr(), N, w_packed.shape[1]))
+        pk = _ROUTES.conv3.get((w_packed.data_ptr(), N, w_packed.shape[1], get_gemm_mode()))
         if pk is not None and x.stride(0) % 4 == 0:
             return conv3x3(x, pk, T, H, W, Cin, N, bias=bias, out=out, alloc=alloc), Ho, Wo
     if out is None:
@@ -420,6 +445,9 @@ class MSDeformAttnFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                 im2col_step=64, is_3d=False):
+        if is_3d:
+            raise NotImplementedError("MSDeformAttnFunction: is_3d=True (the reference's 3-D sampling variant) is not built; "
+                                      "the per-clip path only uses the 2-D op")
         ctx.im2col_step = im2col_step
         out = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                                      attention_weights, im2col_step)
@@ -604,7 +632,7 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
     """Fully explicit form: tensors only provide base pointers (slices / views welcome); all sizes and
     strides (in floats) are given by the caller.  Used by the model for frame-batched launches where the
     addend (a positional map) is shared by all frames (sA2 = 0) or the output is a level slice of [T,S,C]."""
-    if ROWLIN_TABLE and splitk <= 1 and sW == 0 and sBias == 0 and act in (ACT_NONE, ACT_RELU, ACT_GELU):
+    if _ROUTES.rowlin and splitk <= 1 and sW == 0 and sBias == 0 and act in (ACT_NONE, ACT_RELU, ACT_GELU):
         pk = _rowlin_route(w, M, N, K, ldw, batch)
         if pk is not None:
             return rowlin(a, pk, out, M, N, K, lda, ldc, bias=bias, a2=a2, lda2=lda2, act=act, res=res, ldres=ldres,
@@ -636,11 +664,12 @@ def _rowlin_route(w, M, N, K, ldw, batch):
         return None
     if not (K <= 128 and rows >= 32768) and not (K >= 192 and N >= 384 and N != 576):
         return None
-    return ROWLIN_TABLE.get((w.data_ptr(), N, K, ldw))
+    return _ROUTES.rowlin.get((w.data_ptr(), N, K, ldw, get_gemm_mode()))
 
 
 def rowlin_lookup(w, N, K, ldw=None):
-    return ROWLIN_TABLE.get((w.data_ptr(), N, K, K if ldw is None else ldw)) if get_gemm_mode() != "f32" else None
+    mode = get_gemm_mode()
+    return _ROUTES.rowlin.get((w.data_ptr(), N, K, K if ldw is None else ldw, mode)) if mode != "f32" else None
 
 
 # Split-K for the skinny, deep GEMMs of the side branches (RoBERTa at 32 tokens, the decoder on 25 rows); TCE_SPLITK=0
@@ -732,11 +761,51 @@ def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Token-stationary linear layers (csrc/chain.hip: tce_rowlin_f32).  Weights are packed once; the model registers the
-# packed copies of ITS weights here at pack time (keyed by address + shape) and gemm_ex routes eligible launches to
-# the rowlin kernel.  Only registered weights are routed: a key can never go stale under a caller's temporary tensors.
+# Token-stationary linear layers (csrc/chain.hip: tce_rowlin_f32) and the pixel-stationary 3x3 convolution.  Weights
+# are packed once; a MODEL owns the packed copies of its weights in a Routes object (keyed by address + shape + the
+# arithmetic they were packed in) and activates it for the duration of its launch program (`with ops.routes(r):`,
+# pipeline.run_clip); gemm_ex / conv2d_cl route eligible launches through the ACTIVE table only.  Nothing is shared
+# between models (a process-global table let one model's re-pack free streams that another model's captured
+# graphs still pointed to), an entry lives exactly as long as the model's packed weights, and outside a `routes` block
+# (direct ops calls with unrelated tensors) nothing is routed unless the caller registered it in the default table.
 # ---------------------------------------------------------------------------------------------------------------
-ROWLIN_TABLE = {}
+class Routes:
+    def __init__(self):
+        self.rowlin = {}   # (data_ptr, N, K, ldw, mode) of a [N, K] weight -> packed stream
+        self.conv3 = {}    # (data_ptr, N, 9*Cin, mode) of a [N, 9*Cin] weight -> packed stream
+        self.keep = []     # the source weights (views): their addresses are the keys, so they must outlive the entries
+
+    def clear(self):
+        self.rowlin.clear()
+        self.conv3.clear()
+        del self.keep[:]
+
+
+DEFAULT_ROUTES = Routes()  # tools / tests that call the ops directly
+_ROUTES = DEFAULT_ROUTES
+
+
+class routes:
+    """Activates a model's Routes for the launches inside the block."""
+
+    def __init__(self, r):
+        self.r, self.prev = r, None
+
+    def __enter__(self):
+        global _ROUTES
+        self.prev, _ROUTES = _ROUTES, (self.r if self.r is not None else DEFAULT_ROUTES)
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUTES
+        _ROUTES = self.prev
+        return False
+
+
+def current_routes():
+    return _ROUTES
+
+
 ROWLIN_MIN_ROWS = int(os.environ.get("TCE_ROWLIN_MIN_ROWS", 12000))
 ROWLIN_K = (96, 128, 192, 256)
 
@@ -754,14 +823,17 @@ def rowlin_pack(w, N=None, K=None, ldw=None):
     return out
 
 
-def rowlin_register(w):
-    """Packs a model-owned weight [N, K] (row-strided views welcome) and registers it for routing; no-op if ineligible."""
+def rowlin_register(w, table=None):
+    """Packs a weight [N, K] (row-strided views welcome) in the CURRENT arithmetic and registers it in `table` (default: the
+    active Routes); no-op if ineligible."""
     if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] not in ROWLIN_K or w.shape[0] % 32 or not w.is_cuda:
         return None
-    key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0))
-    if key not in ROWLIN_TABLE:
-        ROWLIN_TABLE[key] = rowlin_pack(w)
-    return ROWLIN_TABLE[key]
+    r = _ROUTES if table is None else table
+    key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), get_gemm_mode())
+    if key not in r.rowlin:
+        r.rowlin[key] = rowlin_pack(w)
+        r.keep.append(w)
+    return r.rowlin[key]
 
 
 def rowlin(x, pk, out, M, N, K, ldx, ldo, bias=None, a2=None, lda2=0, a2_rows=0, act=ACT_NONE, res=None, ldres=0,
@@ -800,7 +872,6 @@ def rowlin(x, pk, out, M, N, K, ldx, ldo, bias=None, a2=None, lda2=0, a2_rows=0,
 # ---------------------------------------------------------------------------------------------------------------
 # 3x3 / stride 1 / pad 1 convolution 256 -> 256 as a pixel-stationary launch (csrc/chain.hip: tce_conv3x3_f32)
 # ---------------------------------------------------------------------------------------------------------------
-CONV3_TABLE = {}  # (data_ptr, N, K) of a model-owned [N, 9*Cin] weight -> packed stream
 CONV3_MIN_PIXELS = int(os.environ.get("TCE_CONV3_MIN_PIXELS", 12000))
 
 
@@ -816,13 +887,15 @@ def conv3x3_pack(w_cl, Cin):
     return out
 
 
-def conv3x3_register(w_cl, Cin):
+def conv3x3_register(w_cl, Cin, table=None):
     if lib().tce_conv3x3_packed_bytes(Cin, w_cl.shape[0]) < 0 or w_cl.shape[1] != 9 * Cin:
         return None
-    key = (w_cl.data_ptr(), w_cl.shape[0], w_cl.shape[1])
-    if key not in CONV3_TABLE:
-        CONV3_TABLE[key] = conv3x3_pack(w_cl, Cin)
-    return CONV3_TABLE[key]
+    r = _ROUTES if table is None else table
+    key = (w_cl.data_ptr(), w_cl.shape[0], w_cl.shape[1], get_gemm_mode())
+    if key not in r.conv3:
+        r.conv3[key] = conv3x3_pack(w_cl, Cin)
+        r.keep.append(w_cl)
+    return r.conv3[key]
 
 
 def conv3x3(x, pk, T, H, W, Cin, N, bias=None, out=None, alloc=None):

@@ -77,6 +77,13 @@ class _Fork:
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
              fork3=None):
+    """The clip's launch program with the model's own packed-weight routes active (ops.Routes)."""
+    with ops.routes(model._routes):
+        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3)
+
+
+def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
+              fork3=None):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
@@ -103,7 +110,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     # is a parallel graph branch beside the backbone; its buffers live in the side arena until the end of the clip.
     tA = (side_arena if side_arena is not None else ar).alloc
     text_fork = _Fork(side_stream)
-    with text_fork:
+    with text_fork, model.arith("text"):
         text_hidden, text_pooled = text(tA) if callable(text) else text
         L = text_hidden.shape[0]
         tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
@@ -113,21 +120,24 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
         text_pos = model._text_pos(L, dev)
         xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
 
-        def text_site(pre, rows):
-            """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows."""
+        def text_site(pre, rows, group):
+            """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows.
+            The folded stream is packed in the arithmetic of the site group that consumes it."""
             k = tA(L, D)
             gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
             v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA) \
-                if xattn_ok and rows >= ops.XATTN_MIN_ROWS else None
+            pk = None
+            if xattn_ok and rows >= ops.XATTN_MIN_ROWS:
+                with model.arith(group):
+                    pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA)
             return k, v, pk
 
-        fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1])
+        fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1], "input_proj")
         vl_sites = {}
         if cfg.vlblock:
             for stage in (4, 3, 2, 1):
                 h_, w_ = sizes[stage - 1]
-                vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_)
+                vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_, "pixel.xattn")
 
     _stage("start")
     # ------------------------------------------------------------------ backbone
@@ -136,10 +146,14 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
 
-    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None):
+    def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None, group="encoder.ffn"):
+        with model.arith(group):
+            _ffn(x, M, pre, l1, l2, ar, norm)
+
+    def _ffn(x, M, pre, l1, l2, ar, norm):
         """x <- LN_norm?(x + W2 relu(W1 x)) (in place).  Large M: one fused launch, the [M, 2048] hidden stays on chip
         (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
-        pk = w.get(pre + "ffn:pk") if fused_ok else None
+        pk = w.get(pre + "ffn:pk:" + ops.get_gemm_mode()) if fused_ok else None
         if pk is not None and M >= FFN_FUSED_MIN_ROWS:
             ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
                           ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
@@ -165,6 +179,10 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     lvl_forks = []
 
     def input_level(l, feat, A):
+        with model.arith("input_proj"):
+            _input_level(l, feat, A)
+
+    def _input_level(l, feat, A):
         h, ww = lvl_sizes[l]
         hw = h * ww
         if l < 3:
@@ -207,7 +225,11 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
                     text_fork.join()  # this level's stream waits for the text branch (keys / values of the fusion)
                     input_level(i - 1, feat, arx.alloc)
                 lvl_forks.append(fk_)
-    feats = _resnet_backbone(model, frames, ar, sizes) if cfg.is_resnet else _swin_backbone(model, frames, ar, sizes, on_stage)
+    if cfg.is_resnet:
+        with model.arith("backbone.merge"):  # a ResNet is convolutions only: one site group
+            feats = _resnet_backbone(model, frames, ar, sizes)
+    else:
+        feats = _swin_backbone(model, frames, ar, sizes, on_stage)
 
     _stage("backbone")
     text_fork.join()
@@ -260,7 +282,13 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     tok_stream = side_stream if os.environ.get("TCE_TOKFORK", "1") != "0" else None
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
-             ar=ar, norm=None, small_fork=None):
+             ar=ar, norm=None, small_fork=None, group="encoder.msda"):
+        with model.arith(group):
+            _msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid, ar, norm,
+                  small_fork)
+
+    def _msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
+              ar, norm, small_fork):
         """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D].
         ref may be a callable (evaluated beside value_proj when small_fork is a _Fork: the few-row projections of the
         frame-token path run as a parallel branch next to the large value projection)."""
@@ -308,43 +336,45 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, token_ref, 2, True, token,
                  norm=fp + "norm1", small_fork=_Fork(tok_stream))
             # (2) all T*F tokens attend to each other (:463-469)
-            pre = fp + "token_self_atten."
-            qk = A(T * Fk, 2 * D)
-            fk_v = _Fork(tok_stream)
-            with fk_v:
-                v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
-                    batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
-            fk_v.join()
-            att = A(T * Fk, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, T * Fk, T * Fk, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-            gemm_ex(att, w[pre + "out_proj.weight"], token, T * Fk, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
-                    res=token, ldres=D, res_mode=RES_ADD)
-            ln_(token, fp + "norm2")
-            # (3) every pixel attends to the F tokens of its own frame (:480-484)
-            pre = fp + "frame_token_atten."
-            k = A(T * Fk, D)
-            fk_v = _Fork(tok_stream)
-            with fk_v:
-                v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
-                    sA=Fk * D, sA2=0, sC=Fk * D)
-            fk_v.join()
-            if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
-                # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
-                # launch (the keys / values differ per frame: one folded weight stream per frame)
-                pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], Fk, A, group=8, batch=T)
-                ops.xattn_fused(src, pk, w[pre + "out_proj.bias"], S, src, a2=lvl_pos,
-                                ln_out=(w[fp + "norm3.weight"], w[fp + "norm3.bias"]), batch=T, sX=S * D, sOut=S * D,
-                                group=8, per_batch_weights=True)
-            else:
-                q = A(T * S, D)
-                gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
-                        sA=S * D, sA2=0, sC=S * D)
-                att = A(T * S, D)
-                ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
-                _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
-                             w[fp + "norm3.bias"])
+            with model.arith("encoder.ftf"):
+                pre = fp + "token_self_atten."
+                qk = A(T * Fk, 2 * D)
+                fk_v = _Fork(tok_stream)
+                with fk_v:
+                    v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
+                        batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
+                fk_v.join()
+                att = A(T * Fk, D)
+                ops.mha_core(qk, qk[:, D:], v, 1, NH, T * Fk, T * Fk, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+                gemm_ex(att, w[pre + "out_proj.weight"], token, T * Fk, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
+                        res=token, ldres=D, res_mode=RES_ADD)
+                ln_(token, fp + "norm2")
+                # (3) every pixel attends to the F tokens of its own frame (:480-484)
+                pre = fp + "frame_token_atten."
+                k = A(T * Fk, D)
+                fk_v = _Fork(tok_stream)
+                with fk_v:
+                    v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
+                        sA=Fk * D, sA2=0, sC=Fk * D)
+                fk_v.join()
+            with model.arith("encoder.ftf_x"):
+                if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
+                    # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
+                    # launch (the keys / values differ per frame: one folded weight stream per frame)
+                    pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], Fk, A, group=8, batch=T)
+                    ops.xattn_fused(src, pk, w[pre + "out_proj.bias"], S, src, a2=lvl_pos,
+                                    ln_out=(w[fp + "norm3.weight"], w[fp + "norm3.bias"]), batch=T, sX=S * D, sOut=S * D,
+                                    group=8, per_batch_weights=True)
+                else:
+                    q = A(T * S, D)
+                    gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
+                            sA=S * D, sA2=0, sC=S * D)
+                    att = A(T * S, D)
+                    ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
+                    _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
+                                 w[fp + "norm3.bias"])
             ar.release(m0)
             # (4) FFN over all pixels (:489-491)
             ffn(src, T * S, fp, norm=fp + "norm4")
@@ -386,8 +416,9 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
             gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                     ldres=D, res_mode=RES_ADD)
             ln_(tgt, lp + "norm2")
-            msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar, norm=lp + "norm1")
-            ffn(tgt, T * Q, lp, ar=dar, norm=lp + "norm3")
+            msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar, norm=lp + "norm1",
+                 group="decoder")
+            ffn(tgt, T * Q, lp, ar=dar, norm=lp + "norm3", group="decoder")
             if cfg.with_box_refine:
                 bp = f"bbox_embed.{lid}.layers."
                 t1 = A(T * Q, D)
@@ -424,7 +455,7 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
 
     npar = cfg.num_gen_params
     dec_fork = _Fork(side_stream if side_arena is not None else None)
-    with dec_fork:
+    with dec_fork, model.arith("decoder"):
         hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
         # controller MLP + parameter packing of the dynamic mask head (:371-373, 536-559): depend on hs only, so they
         # ride in the decoder branch instead of the main chain's tail
@@ -450,7 +481,8 @@ def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream
     h4, w4 = sizes[0]
     m0 = ar.mark()
     G = A(T, h4 * w4, nl * Q * 8)
-    ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
+    with model.arith("mask_head"):
+        ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
     masks = A(nl, T, Q, h4, w4)
     ops.mask_tail(G, tail, mask_refs, ref_ld, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
 
@@ -485,9 +517,10 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
     C = cfg.embed_dim
     (H, W) = sizes[0]
     x = A(T * H * W, C)
-    ops.patch_embed(frames, w[b + ("patch_embed.proj.weight:2d" if cfg.video else "patch_embed.proj.weight")],
-                    w[b + "patch_embed.proj.bias"],
-                    w[b + "patch_embed.norm.weight"], w[b + "patch_embed.norm.bias"], out=x)
+    with model.arith("backbone.merge"):
+        ops.patch_embed(frames, w[b + ("patch_embed.proj.weight:2d" if cfg.video else "patch_embed.proj.weight")],
+                        w[b + "patch_embed.proj.bias"],
+                        w[b + "patch_embed.norm.weight"], w[b + "patch_embed.norm.bias"], out=x)
     feats = []
     for i, depth in enumerate(cfg.depths):
         H, W = sizes[i]
@@ -503,36 +536,38 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
             p = f"{b}layers.{i}.blocks.{j}."
             m0 = ar.mark()
             xn = A(ntok, C)
-            qkv = A(ntok, 3 * C)
-            pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
-            if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
-                ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
-                           ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
-            else:
-                ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
-                gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
-            if cfg.video:
-                att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
-                                        W, C, nH, j % 2 == 1, out=xn)
-            else:
-                att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
-                                      C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
-            gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
-                    res_mode=RES_ADD)
-            pk = w.get(p + "mlp.ffn:pk") if ops.get_gemm_mode() != "f32" else None
-            if pk is not None and ntok >= FFN_FUSED_MIN_ROWS:  # norm2 -> fc1 -> GELU -> fc2 -> +x in one launch
-                ops.ffn_fused(x, pk, w[p + "mlp.fc2.bias"], hid, ACT_GELU, M=ntok,
-                              ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
-            else:
-                ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
-                hdn = A(ntok, hid)
-                gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
-                        act=ACT_GELU)
-                # last stage: ~1200 rows against K = 3072 -- 228 workgroups walking 96 K slices each; split-K: 61 -> 41 us
-                sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
-                    if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1
-                gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
-                        ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
+            with model.arith("backbone.attn"):  # x += proj(window attention(qkv(norm1 x)))
+                qkv = A(ntok, 3 * C)
+                pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
+                if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
+                    ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
+                               ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
+                else:
+                    ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
+                    gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
+                if cfg.video:
+                    att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
+                                            W, C, nH, j % 2 == 1, out=xn)
+                else:
+                    att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
+                                          C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
+                gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
+                        res_mode=RES_ADD)
+            with model.arith("backbone.mlp"):  # x += fc2(GELU(fc1(norm2 x)))
+                pk = w.get(p + "mlp.ffn:pk:" + ops.get_gemm_mode()) if ops.get_gemm_mode() != "f32" else None
+                if pk is not None and ntok >= FFN_FUSED_MIN_ROWS:  # norm2 -> fc1 -> GELU -> fc2 -> +x in one launch
+                    ops.ffn_fused(x, pk, w[p + "mlp.fc2.bias"], hid, ACT_GELU, M=ntok,
+                                  ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
+                else:
+                    ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
+                    hdn = A(ntok, hid)
+                    gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
+                            act=ACT_GELU)
+                    # last stage: ~1200 rows against K = 3072 -- 228 workgroups walking 96 K slices each; split-K: 61 -> 41 us
+                    sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
+                        if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1
+                    gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
+                            ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
             ar.release(m0)
         if cfg.video:
             feats.append(x)
@@ -545,7 +580,8 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
             m0 = ar.mark()
             p = f"{b}downsamples.{i}." if cfg.video else f"{b}layers.{i}.downsample."
             xm, _, _ = ops.patch_merge_ln(x, w[p + "norm.weight"], w[p + "norm.bias"], T, H, W, C, alloc=A)
-            gemm_ex(xm, w[p + "reduction.weight"], x_next, x_next.shape[0], 2 * C, 4 * C, 4 * C, 4 * C, 2 * C)
+            with model.arith("backbone.merge"):
+                gemm_ex(xm, w[p + "reduction.weight"], x_next, x_next.shape[0], 2 * C, 4 * C, 4 * C, 4 * C, 2 * C)
             ar.release(m0)
             x = x_next
             C *= 2
@@ -605,13 +641,14 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
     pos = sc["pos"][stage - 1]  # [hw, 256] backbone-level sine map (no level embedding)
     # lateral 1x1 conv (no bias) + GN(8)
     vis = A(T * hw, D)
-    if stage > 1:
-        l = stage - 2  # encoder level index: stage 4 <-> level 2 (32x)
-        gemm_ex(memory[starts[l]:], w[f"{pd}adapter_{stage}.weight"], vis, hw, D, D, D, D, D, batch=T, sA=S * D,
-                sC=hw * D)
-    else:
-        c0 = cfg.num_channels[0]
-        gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
+    with model.arith("pixel.conv"):
+        if stage > 1:
+            l = stage - 2  # encoder level index: stage 4 <-> level 2 (32x)
+            gemm_ex(memory[starts[l]:], w[f"{pd}adapter_{stage}.weight"], vis, hw, D, D, D, D, D, batch=T, sA=S * D,
+                    sC=hw * D)
+        else:
+            c0 = cfg.num_channels[0]
+            gemm_ex(feats[0], w[f"{pd}adapter_1.weight"], vis, T * hw, D, c0, c0, c0, D)
     m1 = arx.mark()
     tgt = ops.groupnorm_cl(vis, w[f"{pd}adapter_{stage}.norm.weight"], w[f"{pd}adapter_{stage}.norm.bias"], T, hw, D, 8,
                            out=vis, alloc=A)
@@ -621,49 +658,51 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
     bp = f"{pd}cross_attn_{stage}."
     pre = bp + "self_attn."
     red = sc["red"].get(stage)
-    m1 = arx.mark()
-    if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
-        nh_, nw_, pos_low = red
-        n_low = T * nh_ * nw_
-        x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
-        qk = A(n_low, 2 * D)
-        gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
-                lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
-        v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
-        att = A(n_low, D)
-        ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
-        o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
-        ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
-    else:
-        n = T * hw
-        qk = A(n, 2 * D)
-        gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
-                batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
-        v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
-        att = A(n, D)
-        ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
-        gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                ldres=D, res_mode=RES_ADD)
-    arx.release(m1)
+    with model.arith("pixel.attn"):
+        m1 = arx.mark()
+        if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
+            nh_, nw_, pos_low = red
+            n_low = T * nh_ * nw_
+            x_low = ops.resize_nearest(tgt, T, h, ww, nh_, nw_, D, alloc=A)
+            qk = A(n_low, 2 * D)
+            gemm_ex(x_low, w[pre + "qk.w"], qk, nh_ * nw_, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos_low,
+                    lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
+            v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(n_low, D)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
+            o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
+            ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
+        else:
+            n = T * hw
+            qk = A(n, 2 * D)
+            gemm_ex(tgt, w[pre + "qk.w"], qk, hw, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=pos, lda2=D,
+                    batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
+            v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            att = A(n, D)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
+            gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                    ldres=D, res_mode=RES_ADD)
+        arx.release(m1)
     ln_(tgt, bp + "norm1")
     # text cross-attention (:366-371)
     pre = bp + "multihead_attn."
-    m1 = arx.mark()
-    tk, tv, pk = vl_sites[stage]
-    if pk is not None:
-        # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
-        ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
-                        ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
-    else:
-        q = A(T * hw, D)
-        gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
-                sA2=0, sC=hw * D)
-        att = A(T * hw, D)
-        ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
-        _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
-                     w[bp + "norm2.bias"])
-    arx.release(m1)
-    ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx)
+    with model.arith("pixel.xattn"):
+        m1 = arx.mark()
+        tk, tv, pk = vl_sites[stage]
+        if pk is not None:
+            # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
+            ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
+                            ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
+        else:
+            q = A(T * hw, D)
+            gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
+                    sA2=0, sC=hw * D)
+            att = A(T * hw, D)
+            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
+                         w[bp + "norm2.bias"])
+        arx.release(m1)
+    ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx, group="pixel.ffn")
     return tgt
 
 
@@ -686,7 +725,8 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
         h, ww = sizes[stage - 1]
         if y is not None:
             ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
-        conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=arx.alloc)
+        with model.arith("pixel.conv"):
+            conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=arx.alloc)
         ops.groupnorm_cl(conv, w[f"{pd}layer_{stage}.norm.weight"], w[f"{pd}layer_{stage}.norm.bias"], T, h * ww, D, 8,
                          relu=True, out=y_new, alloc=arx.alloc)
 
@@ -731,6 +771,7 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
         ar.release(m0)
         y, y_hw = y_new, (h, ww)
     h, ww = sizes[0]
-    out_final, _, _ = ops.conv2d_cl(y, w[pd + "mask_features.weight:cl"], T, h, ww, D, 3, 3, 1, 1,
-                                    bias=w[pd + "mask_features.bias"], alloc=A)
+    with model.arith("pixel.conv"):
+        out_final, _, _ = ops.conv2d_cl(y, w[pd + "mask_features.weight:cl"], T, h, ww, D, 3, 3, 1, 1,
+                                        bias=w[pd + "mask_features.bias"], alloc=A)
     return out_final

@@ -420,10 +420,13 @@ def test_dynamic_mask_head(ops):
 
 
 @pytest.mark.parametrize("T,H,W,nH,shifted", [(3, 18, 25, 3, False), (3, 18, 25, 3, True), (9, 9, 13, 2, True),
-                                               (9, 3, 4, 2, True), (8, 7, 7, 1, True), (17, 8, 6, 1, True)])
+                                               (9, 3, 4, 2, True), (8, 7, 7, 1, True), (17, 8, 6, 1, True),
+                                               # full (8,7,7) windows = 392 keys = 13 key tiles (12 whole + 8 keys), ragged edges
+                                               (8, 16, 23, 2, False), (8, 16, 23, 2, True), (16, 14, 7, 1, True)])
 def test_window_attention_3d(ops, T, H, W, nH, shifted):
     """3-D window attention core against the oracle's Video-Swin block internals (which are pinned to the
-    reference by e2e_vswin_t_small.npz)."""
+    reference by e2e_vswin_t_small.npz): the matrix-core kernel (3 x fp16 split), its single-pass fp16 mode (error
+    class only) and the VALU kernel (exact fp32; the A/B partner and the exact-fp32 mode's kernel)."""
     g = torch.Generator().manual_seed(T * H + W)
     C = nH * 32
     x = torch.randn(1, T, H, W, C, generator=g)  # stands for norm1(x)
@@ -447,9 +450,23 @@ def test_window_attention_3d(ops, T, H, W, nH, shifted):
         y = torch.roll(y, shifts=(ss[0], ss[1], ss[2]), dims=(1, 2, 3))
     ref = y[:, :T, :H, :W].reshape(T * H * W, C)
     qkv = F.linear(x, sd["attn.qkv.weight"], sd["attn.qkv.bias"]).reshape(T * H * W, 3 * C)
-    out = ops.window_attn3d(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
-                            C, nH, shifted)
+    args = (dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W, C, nH, shifted)
+    out = ops.window_attn3d(*args)
     close(out, ref, 1e-4, 1e-4)
+    from tce_rvos_amd._lib import lib
+    lib().tce_debug_window_attn_set_mfma(0)
+    try:
+        out2 = ops.window_attn3d(*args)
+    finally:
+        lib().tce_debug_window_attn_set_mfma(1)
+    close(out2, ref, 1e-4, 1e-4)
+    assert (out - out2).abs().max().item() < 2e-5   # the split keeps the matrix-core kernel fp32-accurate
+    with ops.arith("f16"):
+        out3 = ops.window_attn3d(*args)
+    d3 = (out3.cpu() - ref).abs().max().item()
+    assert 0 < d3 < 2e-2, d3   # one fp16 MFMA per product: fp16-class error, not garbage
+    with ops.arith("f32"):     # exact-fp32 mode runs the VALU kernel: bit-identical to the A/B partner
+        assert torch.equal(ops.window_attn3d(*args), out2)
 
 
 def test_harness_select_masks_matches_reference_caller(ops):

@@ -34,12 +34,12 @@ def time_shape(M, N, K, tile):
     return e0.elapsed_time(e1) / 100 * 1e3
 
 
-saved = dict(ops.ROWLIN_TABLE)
-ops.ROWLIN_TABLE.clear()
+_r = ops.routes(ops.Routes())  # nothing registered: the tiled GEMM
+_r.__enter__()
 for M, N, K in shapes:
     sel = lib().tce_gemm_select_tile_ex(M, N, K, 1, 0)
     res = {t: time_shape(M, N, K, t) for t in TILES}
     print(f"{M}x{N}x{K}: selected {sel}: " + "  ".join(f"{'auto' if t == 0 else t}: {us:6.1f} us" for t, us in res.items()) +
           f"   ({2.0 * M * N * K / res[0] / 1e6:6.1f} TFLOP/s auto)", flush=True)
 lib().tce_gemm_force_tile(0)
-ops.ROWLIN_TABLE.update(saved)
+_r.__exit__()
