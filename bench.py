@@ -16,7 +16,13 @@ Prints ONE JSON line (rank 0).  Extra objects / fields:
                       durations, measured live with events on the launch stream in a second, instrumented (eager) pass
                       (the headline `value` comes from the un-instrumented pass).  `traffic` is NOT measured by this
                       run: it is read from the committed PMC summary named in `traffic_source` (or null).
-  cpu_baseline      : the CPU oracle (a port of the reference path) timed on this box's host cores, rank 0, N=1 only.
+  roofline_hbm      : the dominant HBM-side kernel (the encoder's multi-scale deformable attention call): SURVEY 8d's
+                      algorithmic bytes / its launch duration (same instrumented pass) against the 8 TB/s HBM peak.
+  cpu_baseline      : the CPU oracle (a port of the reference path) timed on this box's host cores, rank 0, N=1 only:
+                      3 timed forwards at min(32, all) threads (`samples`), and one single-thread forward of ONE frame of
+                      the same clip scaled to the clip (`one_thread`).
+  value_c2/value_c4 : clips/s with 2 / 4 independent B=1 forwards in flight per GPU (one stream + replay slot each): the
+                      per-GPU shape of BASELINE config 4 (8 clips per GPU).  The headline `value` is one clip at a time.
   value_f32_exact   : clips/s of the same step with every GEMM on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32) instead
                       of the 3 x fp16 split (N=1 only, short pass).
   value_text_cached : clips/s with the per-expression text cache on (RoBERTa evaluated once per distinct caption
@@ -33,20 +39,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel_prefix):
     """HBM bytes per launch of `kernel_prefix` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same command, aggregated by tools/pmc_traffic.py).  (None, None) when absent."""
-    try:
-        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
-            k = json.load(f)["kernels"]
-        hits = [v for name, v in k.items() if name.startswith(kernel_prefix)]
-        return (round(hits[0]["hbm_bytes_per_launch"]), PMC_SUMMARY + " (rocprofv3 --pmc passes, not this run)") if hits \
-            else (None, None)
-    except Exception:  # noqa: BLE001
-        return None, None
+    for summary in (PMC_SUMMARY, PMC_FALLBACK):
+        try:
+            with open(os.path.join(ROOT, summary)) as f:
+                k = json.load(f)["kernels"]
+            hits = [v for name, v in k.items() if name.startswith(kernel_prefix)]
+            if hits:
+                return round(hits[0]["hbm_bytes_per_launch"]), summary + " (rocprofv3 --pmc passes, not this run)"
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
 
 
 def _ensure_built(local_rank, world):
@@ -81,6 +90,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the value_f32_exact / value_text_cached passes")
     ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3", "f16"],
                     help="f16x3 (default): fp32-accurate 3 x fp16 split; f32: exact fp32 MFMA; f16: one fp16 MFMA per product (config 5)")
+    ap.add_argument("--arith-policy", default="uniform",
+                    help="per-site arithmetic (tce_rvos_amd.model.ARITH_POLICIES): 'uniform' = --gemm-mode everywhere; "
+                         "'cfg5_mixed' = single-pass fp16 in the site groups the committed sensitivity table allows")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (+ TCE_BENCH_ONE_DEVICE=1: every rank on cuda:0) rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--clips-in-flight", type=int, default=1,
@@ -117,6 +129,8 @@ def main():
     model, _, _ = build_model(margs)
     ops.set_gemm_mode(args.gemm_mode)  # before the weights are packed: packed streams carry the mode's rounding
     model = model.to(dev).eval()
+    if args.arith_policy != "uniform":
+        model.set_arith_policy(args.arith_policy)
     C = max(1, args.clips_in_flight)
     if C > 1 and not model.use_graph:
         raise SystemExit("--clips-in-flight > 1 needs graph replay (TCE_GRAPH=1): eager launches share one stream per slot")
@@ -130,7 +144,7 @@ def main():
     ids = ids_host.to(dev)
     targets = [{"size": torch.tensor([H, W])}]
     gather_buf, pending = None, None
-    streams = [torch.cuda.Stream(device=dev) for _ in range(C)] if C > 1 else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(C, 4))]
     use_host_ids = False  # the text-cache pass keys the cache on host ids
 
     def one(i, slot=0):
@@ -186,18 +200,19 @@ def main():
         elapsed = float(tmax.item())
     ops.check_range(dev)  # split-fp16 range guard: a tripped flag invalidates the number
 
-    roofline = None
+    roofline, roofline_hbm = None, None
     C_saved, C = C, 1  # the instrumented pass, the variants and the parity check run one clip at a time
     solo = rank == 0 and world == 1
     if rank == 0 and not args.no_roofline:
         n_inst = min(args.steps, 40)
         graph_mode, model.use_graph = model.use_graph, False  # per-launch events need eager launches
         step(0, gather=False)  # rank-0-only passes must not enter the collective
-        ops.GEMM_PROFILE = []
+        ops.GEMM_PROFILE, ops.HBM_PROFILE = [], []
         for i in range(n_inst):
             step(i, gather=False)
         torch.cuda.synchronize()
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        hprof, ops.HBM_PROFILE = ops.HBM_PROFILE, None
         model.use_graph = graph_mode
         agg = {}
         for tile, conv, flops, e0, e1 in prof:
@@ -231,9 +246,28 @@ def main():
                     "all_mfma_kernels_ms_per_step": round(sum(v[1] for v in agg.values()) / n_inst * 1e3, 3),
                     "all_mfma_kernels_tflops": round(sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12, 2)}
 
+        # HBM side: the encoder's MSDA calls (the launches with the most query rows)
+        if hprof:
+            rows_max = max(h[1] for h in hprof)
+            enc = [h for h in hprof if h[1] == rows_max]
+            hb = sum(h[2] for h in enc)
+            hs = sum(h[3].elapsed_time(h[4]) for h in enc) * 1e-3
+            htraffic, hsrc = _pmc_traffic("msda_fused_q4_kernel")
+            roofline_hbm = {"bound": "hbm", "kernel": "msda_fused_q4_kernel (encoder self-attention call)",
+                            "achieved": round(hb / hs / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(hb / hs / 8e12, 4), "traffic": htraffic, "traffic_source": hsrc,
+                            "launches_per_step": len(enc) // n_inst, "avg_launch_us": round(hs / len(enc) * 1e6, 2),
+                            "bytes_per_launch": hb / len(enc),
+                            "note": "gathers 1.58 GB of bilinear corner rows per launch from the XCD L2s (not algorithmic bytes)"}
+
     variants = {}
     if solo and not args.no_variants:
         n_var = max(10, min(args.steps, 60))
+        if model.use_graph and C_saved == 1:
+            for cc in (2, 4):
+                C = cc
+                variants[f"value_c{cc}"] = round(n_var * cc / timed(n_var, 4, gather=False), 3)
+            C = 1
         model.text_cache_size, use_host_ids = 8, True
         variants["value_text_cached"] = round(n_var / timed(n_var, 6, gather=False), 3)
         model.text_cache_size, use_host_ids = 0, False
@@ -258,13 +292,25 @@ def main():
             bb = BACKBONES[args.backbone]
             cfg = O.OracleConfig(backbone=args.backbone, **{k: bb[k] for k in ("embed_dim", "depths", "num_heads") if k in bb})
             times = []
-            for _ in range(2):
+            for _ in range(4):  # one warm-up + 3 timed forwards
                 t1 = time.perf_counter()
                 ref = O.forward(sd, cfg, frames_cpu, hid, pooled, img_size=(H, W))
                 times.append(time.perf_counter() - t1)
-        cpu_baseline = {"value": round(1.0 / times[-1], 4), "unit": "clips/s", "cores": cores, "kind": "port",
-                        "sample": f"1 clip (T={T}, {H}x{W}, {args.tokens} tokens), 2nd of 2 oracle forwards, "
-                                  f"{times[-1]:.2f} s; text encoder excluded"}
+            times = times[1:]
+            med = sorted(times)[1]
+            # single thread: ONE frame of the same clip (bounded sample), scaled to the clip's T frames
+            torch.set_num_threads(1)
+            t1 = time.perf_counter()
+            O.forward(sd, cfg, frames_cpu[:1], hid, pooled, img_size=(H, W))
+            t_one = (time.perf_counter() - t1) * T
+            torch.set_num_threads(cores)
+        cpu_baseline = {"value": round(1.0 / med, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                        "samples": [round(1.0 / t, 4) for t in times],
+                        "sample": f"1 clip (T={T}, {H}x{W}, {args.tokens} tokens) per sample, median of 3 timed oracle forwards "
+                                  f"after one warm-up ({med:.2f} s); text encoder excluded",
+                        "one_thread": {"value": round(1.0 / t_one, 5), "cores": 1,
+                                       "sample": f"one forward of 1 of the clip's {T} frames on 1 thread, time x {T} "
+                                                 f"({t_one:.1f} s per clip)"}}
         out = step(0, gather=False)
         torch.cuda.synchronize()
         pm = out["pred_masks"].cpu()
@@ -287,7 +333,9 @@ def main():
                 "timed_region_s": round(elapsed, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": {"f32": "f32", "f16x3": "f32 (3xf16-split MFMA, f32 accumulate)",
-                          "f16": "f16 (operands rounded to fp16, one MFMA per product, f32 accumulate)"}[args.gemm_mode],
+                          "f16": "f16 (operands rounded to fp16, one MFMA per product, f32 accumulate)"}[args.gemm_mode] +
+                         ("" if not model.arith_policy else "; single-pass f16 MFMA in site groups " +
+                          ",".join(sorted(g for g, m in model.arith_policy.items() if m == "f16"))),
                 "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
@@ -295,7 +343,8 @@ def main():
                            "parallelism": f"clip-sharded x{world}" +
                                           (" + harness kernel + RCCL all_gather(uint8 masks)" if world > 1 else "")},
                 "launch": "hipGraph replay" if model.use_graph else "eager",
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
+                "graphs": model.graph_state(),
+                "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity}
         line.update(variants)
         print(json.dumps(line), flush=True)
     if world > 1:

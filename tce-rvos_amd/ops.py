@@ -50,6 +50,8 @@ class Arena:
 # When set to a list, every GEMM launch is bracketed by events on the launch stream and
 # (tile, flops, start_event, end_event) is appended: bench.py's live roofline measurement.
 GEMM_PROFILE = None
+# Same for the HBM-bound kernels that report it: (kernel, rows, algorithmic bytes, start_event, end_event).
+HBM_PROFILE = None
 
 
 def _gemm_launch(g, splitk=1, ws=None):
@@ -467,8 +469,19 @@ def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_
     if out is None:
         out = alloc(N * Lq, M * 32) if alloc else torch.empty(N * Lq, M * 32, dtype=torch.float32, device=value.device)
     arr = (C.c_int32 * (2 * L))(*[int(v) for hw in shapes_hw for v in hw])
-    check(lib().tce_msda_fused_f32(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), arr, N, S, M, Lq,
-                                   L, P, ref_dim, 1 if ref_per_frame else 0, _stream()), "tce_msda_fused_f32")
+
+    def go():
+        check(lib().tce_msda_fused_f32(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), arr, N, S, M, Lq,
+                                       L, P, ref_dim, 1 if ref_per_frame else 0, _stream()), "tce_msda_fused_f32")
+    if HBM_PROFILE is None:
+        go()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    # algorithmic bytes: value read once + the 384-wide offsets|weights projection + the output rows
+    HBM_PROFILE.append(("msda_fused_q4_kernel", N * Lq, 4.0 * (N * S * M * 32 + N * Lq * M * L * P * 3 + N * Lq * M * 32), e0, e1))
     return out
 
 
