@@ -110,34 +110,47 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # is a parallel graph branch beside the backbone; its buffers live in the side arena until the end of the clip.
     tA = (side_arena if side_arena is not None else ar).alloc
     text_fork = _Fork(side_stream)
-    with text_fork, model.arith("text"):
-        text_hidden, text_pooled = text(tA) if callable(text) else text
-        L = text_hidden.shape[0]
-        tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-        text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
-        tmp = _lin(tA, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-        sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
-        text_pos = model._text_pos(L, dev)
-        xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
+    L = fk = fv = fpk = sent = None
+    vl_sites = {}
+    text_in = text
 
-        def text_site(pre, rows, group):
-            """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows.
-            The folded stream is packed in the arithmetic of the site group that consumes it."""
-            k = tA(L, D)
-            gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
-            v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
-            pk = None
-            if xattn_ok and rows >= ops.XATTN_MIN_ROWS:
-                with model.arith(group):
-                    pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA)
-            return k, v, pk
+    def text_stage():
+        nonlocal L, fk, fv, fpk, sent
+        with text_fork, model.arith("text"):
+            text_hidden, text_pooled = text_in(tA) if callable(text_in) else text_in
+            L = text_hidden.shape[0]
+            tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+            text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
+            tmp = _lin(tA, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+            sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
+            text_pos = model._text_pos(L, dev)
+            xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
 
-        fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1], "input_proj")
-        vl_sites = {}
-        if cfg.vlblock:
-            for stage in (4, 3, 2, 1):
-                h_, w_ = sizes[stage - 1]
-                vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_, "pixel.xattn")
+            def text_site(pre, rows, group):
+                """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows.
+                The folded stream is packed in the arithmetic of the site group that consumes it."""
+                k = tA(L, D)
+                gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
+                v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                pk = None
+                if xattn_ok and rows >= ops.XATTN_MIN_ROWS:
+                    with model.arith(group):
+                        pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA)
+                return k, v, pk
+
+            fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1], "input_proj")
+            if cfg.vlblock:
+                for stage in (4, 3, 2, 1):
+                    h_, w_ = sizes[stage - 1]
+                    vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_, "pixel.xattn")
+
+
+    # Capture order = submission order of a replay (the graph's nodes are enqueued in the order they were captured): the ~140
+    # few-microsecond launches of the text branch go in AFTER the first Swin stage's, so the backbone (the critical path)
+    # does not queue behind them (TCE_TEXT_LATE=0: text first).
+    text_late = os.environ.get("TCE_TEXT_LATE", "1") != "0" and not cfg.is_resnet
+    if not text_late:
+        text_stage()
 
     _stage("start")
     # ------------------------------------------------------------------ backbone
@@ -212,19 +225,21 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
 
     ar2, stream2 = fork2 if fork2 is not None else (None, None)
     lat1 = None
-    on_stage = None
     if early:
         for arx, _ in fork3:
             arx.reset()
 
-        def on_stage(i, feat):
+    def on_stage(i, feat):
+        if i == 0 and text_late:
+            text_stage()
+        if early:
             if i in (1, 2):
-                arx, stx = fork3[i - 1]
-                fk_ = _Fork(stx)
-                with fk_:
-                    text_fork.join()  # this level's stream waits for the text branch (keys / values of the fusion)
-                    input_level(i - 1, feat, arx.alloc)
-                lvl_forks.append(fk_)
+                    arx, stx = fork3[i - 1]
+                    fk_ = _Fork(stx)
+                    with fk_:
+                        text_fork.join()  # this level's stream waits for the text branch (keys / values of the fusion)
+                        input_level(i - 1, feat, arx.alloc)
+                    lvl_forks.append(fk_)
     if cfg.is_resnet:
         with model.arith("backbone.merge"):  # a ResNet is convolutions only: one site group
             feats = _resnet_backbone(model, frames, ar, sizes)
