@@ -22,6 +22,9 @@ int tce_debug_window_attn_set_mfma(int32_t on);
 /* tuning aid: 1 (default) = tce_mha_f32 runs key sequences >= 256 on the fp16 matrix cores (3 x fp16 split) in GEMM
  * modes 1 / 2; 0 = always the exact fp32-MFMA kernel (A/B timing) */
 int tce_debug_mha_set_split(int32_t on);
+/* tuning aid: 1 (default) = tce_msda_fused_f32 runs calls of <= 8192 (frame, query, head) items with one wavefront per item
+ * (all 16 sampling points in flight); 0 = always 8 lanes per item (A/B timing and parity) */
+int tce_debug_msda_set_fewq(int32_t on);
 #ifdef __cplusplus
 }
 #endif

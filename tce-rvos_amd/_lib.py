@@ -41,6 +41,16 @@ class XattnArgs(C.Structure):
 
 
 
+class FewRowSeg(C.Structure):
+    _fields_ = [("W", c_f), ("bias", c_f), ("out", c_f), ("N", i32), ("ldw", i32), ("ldo", i32), ("use_a2", i32), ("act", i32)]
+
+
+class FewRowArgs(C.Structure):
+    _fields_ = [("x", c_f), ("a2", c_f), ("res", c_f), ("gamma", c_f), ("beta", c_f), ("counter", c_f),
+                ("ldx", i64), ("lda2", i64), ("ldres", i64),
+                ("a2_rows", i32), ("R", i32), ("K", i32), ("nseg", i32), ("eps", f32), ("seg", FewRowSeg * 3)]
+
+
 class CopySeg(C.Structure):
     _fields_ = [("src", c_f), ("dst", c_f), ("rows", i64), ("row_words", i64), ("src_pitch_words", i64)]
 
@@ -99,6 +109,7 @@ SIGNATURES = {
     "tce_conv3x3_packed_bytes": (i64, [i32, i32]),
     "tce_conv3x3_pack_f32": (i32, [c_f, c_f, i32, i32, c_f]),
     "tce_conv3x3_f32": (i32, [c_f, i64, c_f, c_f, c_f, i64, i32, i32, i32, i32, i32, c_f]),
+    "tce_fewrow_linear_f32": (i32, [C.POINTER(FewRowArgs), c_f]),
     "tce_graph_begin": (i32, [c_f]),
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),
@@ -114,6 +125,7 @@ DEBUG_SIGNATURES = {
     "tce_debug_msda_set_lds": (i32, [i32]),
     "tce_debug_window_attn_set_mfma": (i32, [i32]),
     "tce_debug_mha_set_split": (i32, [i32]),
+    "tce_debug_msda_set_fewq": (i32, [i32]),
 }
 
 _LIB = None

@@ -906,13 +906,14 @@ __global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restr
                                                             const float* __restrict__ qkv_bias,
                                                             const float* __restrict__ table, float* __restrict__ out,
                                                             Win3D g, int C, int nH, int table_rows) {
-  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  // static LDS, sized for the nominal 8x7x7 window (no hipFuncAttributeMaxDynamicSharedMemorySize call on the launch path)
+  constexpr int NMAX = 8 * 7 * 7, TROWS = 15 * 13 * 13;
+  __shared__ __attribute__((aligned(16))) float sK[NMAX * HD];  // [N][32]
+  __shared__ __attribute__((aligned(16))) float sV[NMAX * HD];  // [N][32]
+  __shared__ float sB[TROWS];
+  __shared__ int sSrc[NMAX];  // [N] source token row or -1 (padded)
+  __shared__ int sRid[NMAX];  // [N] mask region id
   const int N = g.wd * g.wh * g.ww;
-  float* sK = smem3;                 // [N][32]
-  float* sV = sK + N * HD;           // [N][32]
-  float* sB = sV + N * HD;           // [table_rows]
-  int* sSrc = reinterpret_cast<int*>(sB + table_rows);  // [N] source token row or -1 (padded)
-  int* sRid = sSrc + N;              // [N] mask region id
   const int tid = threadIdx.x;
   const int h = blockIdx.x % nH;
   int widx = blockIdx.x / nH;
@@ -1055,17 +1056,13 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
                                                                      int table_rows, int NKP, const int single) {
   typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem3m[];
-  constexpr int KPITCH = 80;
-  const int VPITCH = NKP * 2 + 8;
+  // static LDS sized for the nominal window (392 keys -> 416): 134 KB, one workgroup per CU
+  constexpr int KPITCH = 80, NKMAX = 416, VPITCH = NKMAX * 2 + 8, TROWS = 15 * 13 * 13;
+  __shared__ __attribute__((aligned(16))) unsigned char sKh[NKMAX * KPITCH], sKl[NKMAX * KPITCH], sVh[HD * VPITCH], sVl[HD * VPITCH];
+  __shared__ float sB[TROWS + 1];
+  __shared__ int sSrc[NKMAX];  // source token row, -1 padded token, -2 no token
+  __shared__ int sCR[NKMAX];   // code | region id << 16
   const int N = g.wd * g.wh * g.ww;
-  unsigned char* const sKh = smem3m;
-  unsigned char* const sKl = sKh + NKP * KPITCH;
-  unsigned char* const sVh = sKl + NKP * KPITCH;
-  unsigned char* const sVl = sVh + HD * VPITCH;
-  float* const sB = reinterpret_cast<float*>(sVl + HD * VPITCH);
-  int* const sSrc = reinterpret_cast<int*>(sB + ((table_rows + 3) & ~3));  // [NKP] source token row, -1 padded token, -2 no token
-  int* const sCR = sSrc + NKP;                                            // [NKP] code | region id << 16
   const int tid = threadIdx.x, nthr = 64 * NW;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -1375,33 +1372,18 @@ extern "C" int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, co
   const int N = g.wd * g.wh * g.ww;
   const int table_rows = (2 * 8 - 1) * 13 * 13;
   const int nwin = (g.Dp / g.wd) * (g.Hp / g.wh) * (g.Wp / g.ww);
-  const size_t smem = (size_t)(2 * N * 32 + table_rows) * sizeof(float) + (size_t)2 * N * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn3d_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  TCE_CHECK_ARG(N <= 392 && table_rows == 15 * 13 * 13, "tce_window_attn3d_f32: window larger than the nominal (8,7,7)");
   if (g_window_attn_mfma && tce_get_gemm_mode() != 0) {
     // fp16 matrix cores (3 x fp16 split; mode 2: single pass).  8 waves per workgroup: two per SIMD, so one wave's softmax
     // (VALU) runs under the other's MFMAs; the 13 query tiles of a full window take two rounds.
     constexpr int NW = 8;
     const int NKP = (N + 31) / 32 * 32;
-    const size_t smem_m = (size_t)2 * NKP * 80 + (size_t)2 * 32 * (NKP * 2 + 8) + (size_t)((table_rows + 3) & ~3) * 4 +
-                          (size_t)2 * NKP * 4;
-    static bool attr_set_m = false;
-    if (!attr_set_m) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn3d_mfma_kernel<NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set_m = true;
-    }
-    TCE_CHECK_ARG(smem_m <= 160 * 1024, "tce_window_attn3d_f32: window does not fit the LDS");
-    hipLaunchKernelGGL(window_attn3d_mfma_kernel<NW>, dim3(nwin * nH), dim3(64 * NW), smem_m, (hipStream_t)stream, qkv,
+    hipLaunchKernelGGL(window_attn3d_mfma_kernel<NW>, dim3(nwin * nH), dim3(64 * NW), 0, (hipStream_t)stream, qkv,
                        qkv_bias, bias_table, out, g, C, nH, table_rows, NKP, tce_gemm_single_pass());
     TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
     return TCE_OK;
   }
-  hipLaunchKernelGGL(window_attn3d_kernel, dim3(nwin * nH), dim3(256), smem, (hipStream_t)stream, qkv, qkv_bias,
+  hipLaunchKernelGGL(window_attn3d_kernel, dim3(nwin * nH), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
                      bias_table, out, g, C, nH, table_rows);
   TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
   return TCE_OK;

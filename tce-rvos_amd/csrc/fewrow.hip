@@ -1,0 +1,242 @@
+// Few-row linear layers (a few dozen rows): the frame-token path of the encoder (T*F = 40 rows at config 2,
+// tce_deformable_transformer.py:443-484), the decoder's per-query projections (T*Q = 25 rows, :665-790) and the text-side
+// key / value projections (<= 32 rows, segmentation.py:366-371).  On the tiled matrix-core GEMM such a launch is one
+// pipeline fill long (7-12 us for 5 MFLOP) and each LayerNorm / sigmoid / second projection of the same rows is another
+// launch; these sit on the clip's critical path between two encoder layers (0.54 ms per clip by ablation,
+// profiles/r03_ablate_cfg2.txt).
+//
+//   out_s[r, n] = act_s( sum_k (x[r,k] (+ a2[r % a2_rows, k] if the segment asks)) W_s[n,k] + b_s[n] )      s < nseg <= 3
+//   optional, segment 0 only:  out_0 = LayerNorm(res + out_0) * gamma + beta
+//
+// Exact fp32 on the vector ALUs (fmaf chains in k order: no operand splitting, no range contract).  One launch serves up to
+// three projections of the SAME rows (q|k with the position map added and v without; reference points through a sigmoid
+// beside the offsets|weights projection).  A workgroup owns an 8-column slab of one segment and up to 64 rows: x rows
+// (+ addend) and the W slab are staged in LDS with full-line loads, thread (column c, row group g) accumulates rows
+// g, g+32 with broadcast reads of x.  More slabs than CUs are never needed here (N <= 1024), so the launch is one
+// wave of workgroups and costs about one memory round trip + R*16*K/256 FMAs per thread.
+// LayerNorm epilogue without a second launch: every slab workgroup of segment 0 writes res + linear to `out`, publishes it
+// (threadfence + one atomic on a per-row-block counter) and the LAST arriver normalises the finished rows (after an
+// agent-scope acquire fence, which invalidates its non-coherent L1) and resets the counter.  No workgroup ever waits for another: legal
+// inside a hipGraph next to anything, deterministic (one workgroup reduces complete rows in a fixed order).
+#include "common.h"
+#include "../../include/tce_rvos.h"
+
+namespace {
+
+constexpr int FR_COLS = 8;     // columns per slab
+constexpr int FR_KC = 256;     // K chunk staged at a time
+constexpr int FR_PITCH = FR_KC + 4;
+
+struct FrSegDev {
+  const float* W;
+  const float* bias;
+  float* out;
+  int N, ldw, ldo, use_a2, act, slab0;  // slab0: first slab index of this segment
+};
+
+struct FrArgs {
+  const float* x;
+  const float* a2;
+  const float* res;
+  const float* gamma;
+  const float* beta;
+  unsigned* counter;
+  long long ldx, lda2, ldres;
+  int a2_rows, R, K, nseg, ln;
+  float eps;
+  FrSegDev seg[3];
+};
+
+// Thread (column c = tid & 7, row group g = tid >> 3) owns row g of the workgroup's 32-row pass (RPT = 1).  Rows past the
+// end are staged as zeros, so the inner loop has no branches and its LDS reads can be issued ahead of the FMAs (a first
+// version with per-row guards ran one LDS round trip per FMA group: 13 us for a 25 x 256 x 4 problem).
+// A 64-row-per-workgroup variant (RPT = 2) was built and REMOVED: replayed inside the clip's hipGraph beside the pixel
+// decoder's lateral branch it made the frame-token state differ from run to run (the replay-equals-eager tests caught it; 32-row
+// passes never did in 35 replays); not reproduced at kernel level (tools/concurrency_probe.py), cause not established.
+template <int RPT>
+__global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
+  __shared__ __attribute__((aligned(16))) float sX[32 * RPT * FR_PITCH];
+  __shared__ __attribute__((aligned(16))) float sW[FR_COLS * FR_PITCH];
+  __shared__ unsigned sLast;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int s = 0;
+  if (p.nseg > 1 && (int)blockIdx.x >= p.seg[1].slab0) s = 1;
+  if (p.nseg > 2 && (int)blockIdx.x >= p.seg[2].slab0) s = 2;
+  const FrSegDev sg = s == 0 ? p.seg[0] : (s == 1 ? p.seg[1] : p.seg[2]);
+  const int n0 = ((int)blockIdx.x - sg.slab0) * FR_COLS;
+  const int r0 = blockIdx.y * (32 * RPT);
+  const int nr = min(32 * RPT, p.R - r0);
+  const int c = tid & 7, g = tid >> 3;
+  float acc[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += FR_KC) {
+    const int kc = min(FR_KC, p.K - k0);  // multiple of 4
+    const int q4 = kc >> 2;               // float4 per row (<= 64)
+    if (k0) __syncthreads();
+    // x rows (+ addend), zero rows past the end: thread t moves piece (t & 63) of rows (t >> 6), +4, ...
+    if ((tid & 63) < q4) {
+      const int q = tid & 63;
+      for (int r = tid >> 6; r < 32 * RPT; r += 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < nr) {
+          v = *reinterpret_cast<const f32x4*>(p.x + (long long)(r0 + r) * p.ldx + k0 + 4 * q);
+          if (sg.use_a2) {
+            const int ra = p.a2_rows > 0 ? (r0 + r) % p.a2_rows : r0 + r;
+            v += *reinterpret_cast<const f32x4*>(p.a2 + (long long)ra * p.lda2 + k0 + 4 * q);
+          }
+        }
+        *reinterpret_cast<f32x4*>(&sX[r * FR_PITCH + 4 * q]) = v;
+      }
+      for (int r = tid >> 6; r < FR_COLS; r += 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + r < sg.N) v = *reinterpret_cast<const f32x4*>(sg.W + (long long)(n0 + r) * sg.ldw + k0 + 4 * q);
+        *reinterpret_cast<f32x4*>(&sW[r * FR_PITCH + 4 * q]) = v;
+      }
+    }
+    __syncthreads();
+    const float* wrow = &sW[c * FR_PITCH];
+    const float* xrow = &sX[g * FR_PITCH];
+    if (q4 == 64) {
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + i * 32 * FR_PITCH + 4 * q);
+          acc[i] = fmaf(xv[0], wv[0], acc[i]);
+          acc[i] = fmaf(xv[1], wv[1], acc[i]);
+          acc[i] = fmaf(xv[2], wv[2], acc[i]);
+          acc[i] = fmaf(xv[3], wv[3], acc[i]);
+        }
+      }
+    } else {
+      for (int q = 0; q < q4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + i * 32 * FR_PITCH + 4 * q);
+          acc[i] = fmaf(xv[0], wv[0], acc[i]);
+          acc[i] = fmaf(xv[1], wv[1], acc[i]);
+          acc[i] = fmaf(xv[2], wv[2], acc[i]);
+          acc[i] = fmaf(xv[3], wv[3], acc[i]);
+        }
+      }
+    }
+  }
+  const int n = n0 + c;
+  const bool with_ln = p.ln && s == 0;
+  if (n < sg.N) {
+    const float bv = sg.bias ? sg.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = g + 32 * i;
+      if (r < nr) {
+        float v = acc[i] + bv;
+        if (sg.act == 1) v = fmaxf(v, 0.f);
+        if (sg.act == 2) v = 1.0f / (1.0f + __expf(-v));
+        if (sg.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (s == 0 && p.res) v += p.res[(long long)(r0 + r) * p.ldres + n];
+        sg.out[(long long)(r0 + r) * sg.ldo + n] = v;
+      }
+    }
+  }
+  if (!with_ln) return;
+  // publish the slab; the last arriver of this row block normalises its rows
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned nslabs = (unsigned)((sg.N + FR_COLS - 1) / FR_COLS);
+    const unsigned old = atomicAdd(p.counter + blockIdx.y, 1u);
+    sLast = (old == nslabs - 1) ? 1u : 0u;
+    if (sLast) p.counter[blockIdx.y] = 0u;  // ready for the next launch (stream order separates the launches)
+  }
+  __syncthreads();
+  if (!sLast) return;
+  // acquire at agent scope: invalidates this CU's (non-coherent) L1, so the plain, pipelinable loads below see the other
+  // workgroups' slabs.  (Per-element atomic loads were one dependent L2 round trip per row: 20 us for 40 rows.)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int N = sg.N;
+  const float invN = 1.0f / (float)N;
+  // a wave normalises rows wave, wave+4, ...; two rows per step so that their loads are in flight together
+  for (int rb = wave; rb < nr; rb += 8) {
+    float v[2][16];  // N <= 1024
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = rb + 4 * u;
+      const float* row = sg.out + (long long)(r0 + min(r, nr - 1)) * sg.ldo;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int col = lane + 64 * j;
+        v[u][j] = (col < N) ? row[col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum[u] += v[u][j];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = rb + 4 * u;
+      const float mean = wave_sum(sum[u]) * invN;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int col = lane + 64 * j;
+        const float d = col < N ? v[u][j] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+      }
+      const float rstd = rsqrtf(wave_sum(sq) * invN + p.eps);
+      if (r < nr) {
+        float* row = sg.out + (long long)(r0 + r) * sg.ldo;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int col = lane + 64 * j;
+          if (col < N) row[col] = (v[u][j] - mean) * rstd * p.gamma[col] + p.beta[col];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
+  TCE_CHECK_ARG(a && a->x && a->nseg >= 1 && a->nseg <= 3, "tce_fewrow_linear_f32: bad arguments");
+  TCE_CHECK_ARG(a->R > 0 && a->K > 0 && a->K % 4 == 0 && a->ldx % 4 == 0 && tce_aligned16(a->x),
+                "tce_fewrow_linear_f32: K and ldx must be multiples of 4, x 16-byte aligned");
+  FrArgs p;
+  p.x = a->x; p.a2 = a->a2; p.res = a->res; p.gamma = a->gamma; p.beta = a->beta; p.counter = a->counter;
+  p.ldx = a->ldx; p.lda2 = a->lda2; p.ldres = a->ldres;
+  p.a2_rows = a->a2_rows; p.R = a->R; p.K = a->K; p.nseg = a->nseg; p.eps = a->eps;
+  p.ln = (a->gamma != nullptr) ? 1 : 0;
+  int slabs = 0;
+  for (int s = 0; s < 3; ++s) {
+    FrSegDev& d = p.seg[s];
+    d = FrSegDev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 1 << 30};
+    if (s >= a->nseg) continue;
+    const tceFewRowSeg& g = a->seg[s];
+    TCE_CHECK_ARG(g.W && g.out && g.N > 0 && g.ldw % 4 == 0 && g.ldw >= a->K && g.ldo >= g.N && tce_aligned16(g.W),
+                  "tce_fewrow_linear_f32: segment %d: bad weight / output geometry", s);
+    TCE_CHECK_ARG(!g.use_a2 || (a->a2 && a->lda2 % 4 == 0 && tce_aligned16(a->a2)), "tce_fewrow_linear_f32: addend missing / misaligned");
+    TCE_CHECK_ARG(g.act >= 0 && g.act <= 3, "tce_fewrow_linear_f32: act must be 0 (none), 1 (ReLU), 2 (sigmoid) or 3 (GELU)");
+    {  // every workgroup re-reads the x rows while others store: an output must not overlap them
+      const float *xb = a->x, *xe = a->x + (long long)(a->R - 1) * a->ldx + a->K;
+      const float *ob = g.out, *oe = g.out + (long long)(a->R - 1) * g.ldo + g.N;
+      TCE_CHECK_ARG(oe <= xb || xe <= ob, "tce_fewrow_linear_f32: segment %d: out overlaps x", s);
+    }
+    d.W = g.W; d.bias = g.bias; d.out = g.out; d.N = g.N; d.ldw = g.ldw; d.ldo = g.ldo; d.use_a2 = g.use_a2; d.act = g.act;
+    d.slab0 = slabs;
+    slabs += tce_cdiv(g.N, FR_COLS);
+  }
+  if (p.ln) {
+    TCE_CHECK_ARG(a->beta && a->counter && a->seg[0].N <= 1024, "tce_fewrow_linear_f32: LayerNorm epilogue needs beta, a zeroed "
+                  "counter word per 32 rows and N <= 1024");
+    TCE_CHECK_ARG(a->seg[0].act == 0, "tce_fewrow_linear_f32: LayerNorm epilogue takes no activation");
+  }
+  TCE_CHECK_ARG(!a->res || a->ldres >= a->seg[0].N, "tce_fewrow_linear_f32: residual pitch");
+  hipLaunchKernelGGL(fewrow_linear_kernel<1>, dim3(slabs, tce_cdiv(a->R, 32)), dim3(256), 0, (hipStream_t)stream, p);
+  TCE_CHECK_LAUNCH("tce_fewrow_linear_f32");
+  return TCE_OK;
+}

@@ -540,6 +540,92 @@ __global__ void __launch_bounds__(256) msda_backward_kernel(const float* __restr
   }
 }
 
+// Few-query form (the frame tokens' and the decoder queries' calls: a few dozen (frame, query) pairs x 8 heads): one
+// WAVEFRONT per (frame, query, head) item instead of 8 lanes walking the 16 sampling points one after the other -- lane =
+// (point p = lane >> 2, channel octet lane & 3), so all 16 points' four corner rows (2 x 16 bytes per lane and corner) are
+// in flight at once and the call costs one memory round trip instead of sixteen.  Softmax over the points and the final
+// sum over them are xor-shuffles across the point index (strides 4..32).  Same bilinear rule, different summation order
+// than the 8-lane form (tree over points instead of sequential).
+__global__ void __launch_bounds__(256) msda_fused_fewq_kernel(const float* __restrict__ value, const float* __restrict__ proj,
+                                                              const float* __restrict__ ref, float* __restrict__ out,
+                                                              LevelInfo lv, int N, int S, int M, int Lq, int L, int P,
+                                                              int ref_dim, int ref_per_frame, long long total) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (n*Lq + q)*M + m
+  if (item >= total) return;  // whole wave
+  const int pj = lane >> 2, cq = lane & 3;
+  const int LP = L * P;
+  long long r = item;
+  const int m = (int)(r % M); r /= M;
+  const int q = (int)(r % Lq);
+  const int n = (int)(r / Lq);
+  const bool have = pj < LP;
+  float px = 0.f, py = 0.f, logit = -3.0e38f;
+  int l = 0;
+  if (have) {
+    l = pj / P;
+    const float* row = proj + ((long long)n * Lq + q) * (M * LP * 3);
+    const float ox = row[(m * LP + pj) * 2 + 0];
+    const float oy = row[(m * LP + pj) * 2 + 1];
+    logit = row[M * LP * 2 + m * LP + pj];
+    const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+    if (ref_dim == 2) {
+      px = rp[0] + ox / (float)lv.W[l];
+      py = rp[1] + oy / (float)lv.H[l];
+    } else {
+      px = rp[0] + ox / (float)P * rp[2] * 0.5f;
+      py = rp[1] + oy / (float)P * rp[3] * 0.5f;
+    }
+  }
+  float mx = logit;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float e = have ? __expf(logit - mx) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float wgt = e / sum;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (have) {
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const float h_im = py * (float)Hl - 0.5f, w_im = px * (float)Wl - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+      const long long row_stride = (long long)M * D;
+      const float* vbase = value + ((long long)n * S + lv.start[l]) * row_stride + m * D + cq * 8;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v[4][2] = {{z, z}, {z, z}, {z, z}, {z, z}};
+      const bool ok[4] = {h_low >= 0 && w_low >= 0, h_low >= 0 && w_high <= Wl - 1, h_high <= Hl - 1 && w_low >= 0,
+                          h_high <= Hl - 1 && w_high <= Wl - 1};
+      const long long pos[4] = {(long long)h_low * Wl + w_low, (long long)h_low * Wl + w_high, (long long)h_high * Wl + w_low,
+                                (long long)h_high * Wl + w_high};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (ok[c]) {
+          const float* pv = vbase + pos[c] * row_stride;
+          v[c][0] = *reinterpret_cast<const f32x4*>(pv);
+          v[c][1] = *reinterpret_cast<const f32x4*>(pv + 4);
+        }
+      const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[i] = wgt * (c1 * v[0][i >> 2][i & 3] + c2 * v[1][i >> 2][i & 3] + c3 * v[2][i >> 2][i & 3] + c4 * v[3][i >> 2][i & 3]);
+    }
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+  if (pj == 0) {
+    float* po = out + item * D + cq * 8;
+    *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
 }  // namespace
 
 extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -603,6 +689,12 @@ extern "C" int tce_debug_msda_set_lds(int32_t on) {
   return TCE_OK;
 }
 
+static int g_msda_fewq = 1;
+extern "C" int tce_debug_msda_set_fewq(int32_t on) {
+  g_msda_fewq = on;
+  return TCE_OK;
+}
+
 extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const float* ref, float* out,
                                   const int32_t* shapes_hw, int32_t N, int32_t S, int32_t M, int32_t Lq, int32_t L,
                                   int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream) {
@@ -641,6 +733,12 @@ extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const f
       TCE_CHECK_LAUNCH("tce_msda_fused_f32(lds)");
       return TCE_OK;
     }
+  }
+  if (g_msda_fewq && tce_aligned16(value) && tce_aligned16(out) && total <= 8192) {  // few queries: one wave per item, all points in flight
+    hipLaunchKernelGGL(msda_fused_fewq_kernel, dim3(tce_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out,
+                       lv, N, S, M, Lq, L, P, ref_dim, ref_per_frame, total);
+    TCE_CHECK_LAUNCH("tce_msda_fused_f32(fewq)");
+    return TCE_OK;
   }
   if (tce_aligned16(value) && tce_aligned16(out)) {  // 16-byte form: 32 items per workgroup
     const int nb = (M == 8) ? tce_cdiv((long long)N * Lq, 32) * 8 : tce_cdiv(total, 32);

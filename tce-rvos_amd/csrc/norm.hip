@@ -523,19 +523,11 @@ extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const fl
     TCE_CHECK_LAUNCH("tce_patch_embed_f32");
     return TCE_OK;
   }
-  if (C % 8 == 0 && C <= 152 && tce_aligned16(frames) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta)) {
+  // (C <= 120: the lane kernel's dynamic LDS stays below the 64 KB a launch may request without raising the function's
+  // limit; wider embeddings take the generic kernel below.)
+  if (C % 8 == 0 && C <= 120 && tce_aligned16(frames) && tce_aligned16(out) && tce_aligned16(gamma) && tce_aligned16(beta)) {
     constexpr int TOK = 128;  // tokens (= threads) per workgroup: 52 KiB of LDS at C = 96 -> three workgroups per CU
     const size_t lds = (size_t)(TOK * (C + 4) + 2 * TOK) * sizeof(float);
-    static size_t lds_allowed = 64 * 1024;  // dynamic LDS above 64 KiB has to be requested once per function
-    if (lds > lds_allowed) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_embed_lane_kernel<8, TOK>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        tce_set_error("tce_patch_embed_f32: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        return TCE_ELAUNCH;
-      }
-      lds_allowed = 160 * 1024;
-    }
     hipLaunchKernelGGL((patch_embed_lane_kernel<8, TOK>), dim3(tce_cdiv(ntok, TOK)), dim3(TOK), lds, (hipStream_t)stream, frames, w, b,
                        gamma, beta, out, H, W, C, eps, ntok, Hp, Wp);
     TCE_CHECK_LAUNCH("tce_patch_embed_f32");

@@ -70,49 +70,55 @@ __global__ void __launch_bounds__(128) mha_small_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(&sV[j * HDIM + d4 * 4]) = *reinterpret_cast<const f32x4*>(p + 2 * E);
   }
   __syncthreads();
-  const int i = tid;
-  if (i >= L) return;
-  float q[HDIM];
+  // four lanes per query (a quarter of the head dim each): the score is a 16-term partial dot + two shuffles, the output
+  // row is split the same way -- a thread per query walked the keys with 128 dependent FMAs each (19 us for 32 tokens)
+  constexpr int QD = HDIM / 4;
+  const int i = blockIdx.y * 32 + (tid >> 2), part = tid & 3;
+  const int ic = min(i, L - 1);
+  float q[QD];
   {
-    const float* p = qkv + (long long)i * 3 * E + h * HDIM;
+    const float* p = qkv + (long long)ic * 3 * E + h * HDIM + part * QD;
 #pragma unroll
-    for (int d4 = 0; d4 < HDIM / 4; ++d4) {
+    for (int d4 = 0; d4 < QD / 4; ++d4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) q[d4 * 4 + c] = v[c] * scale;
     }
   }
   float m = -3.0e38f, l = 0.f;
-  float o[HDIM];
+  float o[QD];
 #pragma unroll
-  for (int d = 0; d < HDIM; ++d) o[d] = 0.f;
+  for (int d = 0; d < QD; ++d) o[d] = 0.f;
   for (int j = 0; j < L; ++j) {  // online softmax, one key at a time (L is tiny)
-    const f32x4* kp = reinterpret_cast<const f32x4*>(&sK[j * HDIM]);
+    const f32x4* kp = reinterpret_cast<const f32x4*>(&sK[j * HDIM + part * QD]);
     float a = 0.f;
 #pragma unroll
-    for (int d4 = 0; d4 < HDIM / 4; ++d4) {
+    for (int d4 = 0; d4 < QD / 4; ++d4) {
       const f32x4 kv = kp[d4];
       a = fmaf(q[d4 * 4 + 0], kv[0], a);
       a = fmaf(q[d4 * 4 + 1], kv[1], a);
       a = fmaf(q[d4 * 4 + 2], kv[2], a);
       a = fmaf(q[d4 * 4 + 3], kv[3], a);
     }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
     const float mnew = fmaxf(m, a);
     const float corr = __expf(m - mnew), pj = __expf(a - mnew);
     l = l * corr + pj;
-    const f32x4* vp = reinterpret_cast<const f32x4*>(&sV[j * HDIM]);
+    const f32x4* vp = reinterpret_cast<const f32x4*>(&sV[j * HDIM + part * QD]);
 #pragma unroll
-    for (int d4 = 0; d4 < HDIM / 4; ++d4) {
+    for (int d4 = 0; d4 < QD / 4; ++d4) {
       const f32x4 vv = vp[d4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) o[d4 * 4 + c] = fmaf(pj, vv[c], o[d4 * 4 + c] * corr);
     }
     m = mnew;
   }
+  if (i >= L) return;
   const float inv = 1.f / l;
-  float* po = out + (long long)i * E + h * HDIM;
+  float* po = out + (long long)i * E + h * HDIM + part * QD;
 #pragma unroll
-  for (int d4 = 0; d4 < HDIM / 4; ++d4) {
+  for (int d4 = 0; d4 < QD / 4; ++d4) {
     f32x4 v = {o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv};
     *reinterpret_cast<f32x4*>(po + d4 * 4) = v;
   }
@@ -141,8 +147,8 @@ extern "C" int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int3
   TCE_CHECK_ARG(qkv && out && nheads > 0, "tce_mha_small64_f32: bad arguments");
   TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_f32: sequence length %d outside 1..128", L);
   TCE_CHECK_ARG(tce_aligned16(qkv) && tce_aligned16(out), "tce_mha_small64_f32: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads), dim3(128), 0, (hipStream_t)stream, qkv, out, L, nheads,
-                     scale);
+  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(128), 0, (hipStream_t)stream, qkv, out, L,
+                     nheads, scale);
   TCE_CHECK_LAUNCH("tce_mha_small64_f32");
   return TCE_OK;
 }

@@ -37,6 +37,11 @@ def _lin(A, x, M, K, w, b, N, **kw):
     return out
 
 
+# Diagnostic (tools/ablate_times.py): stages named in TCE_ABLATE are SKIPPED -- results are then garbage; the time that
+# disappears is the stage's share of the clip's critical path (what optimising it to zero would buy).
+ABLATE = set(filter(None, os.environ.get("TCE_ABLATE", "").split(",")))
+
+
 # Diagnostic: when set to a list, run_clip appends (stage name, event recorded on the main stream at the END of the
 # stage) -- tools/stage_times.py (eager mode only).
 STAGE_EVENTS = None
@@ -103,6 +108,19 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     sizes, lvl_sizes, S, starts = sc["sizes"], sc["lvl_sizes"], sc["S"], sc["starts"]
     Q = cfg.num_queries
     ff = cfg.dim_feedforward
+    # Few-row kernel (csrc/fewrow.hip): the per-token / per-query projections (a few dozen rows, K = 256) as exact-fp32 launches
+    # that serve several projections of the same rows at once (TCE_FEWROW=0: tiled GEMMs).  Its LayerNorm epilogue is NOT
+    # used here: finishing the rows in the last workgroup needs an agent-scope release / acquire, which on this 8-XCD part is
+    # an L2 write-back + invalidate -- 19 us, more than the LayerNorm launch it saves (profiles/r03_fewrow.txt).
+    few_ok = os.environ.get("TCE_FEWROW", "1") != "0"
+    FR = ops.fewrow_linear
+
+    few_sites = os.environ.get("TCE_FEWROW_SITES")  # bisect aid: comma list of msda,ftf2,ftf3,dec,text (default: all)
+
+    def few(rows, site=None):
+        if few_sites is not None and site not in few_sites.split(","):
+            return False
+        return few_ok and rows <= ops.FEWROW_MAX_ROWS
 
     # ------------------------------------------------------------------ text stage (tce_rvos.py:406-424, FeatureResizer
     # :616-635) and everything that depends on the text alone: the projected keys / values of the five text
@@ -130,8 +148,13 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows.
                 The folded stream is packed in the arithmetic of the site group that consumes it."""
                 k = tA(L, D)
-                gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
-                v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                if few(L, "text"):  # key (text + position) and value projections of the site in one launch
+                    v = tA(L, D)
+                    FR(text, L, D, [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, 0), (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, 0)],
+                       a2=text_pos, lda2=D)
+                else:
+                    gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
+                    v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
                 pk = None
                 if xattn_ok and rows >= ops.XATTN_MIN_ROWS:
                     with model.arith(group):
@@ -160,6 +183,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     fused_ok = ops.get_gemm_mode() != "f32"  # the fused kernels ARE split-fp16 arithmetic; exact-fp32 mode = GEMM path
 
     def ffn(x, M, pre, l1="linear1", l2="linear2", ar=ar, norm=None, group="encoder.ffn"):
+        if "ffn:" + group in ABLATE:
+            return
         with model.arith(group):
             _ffn(x, M, pre, l1, l2, ar, norm)
 
@@ -305,11 +330,37 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     def _msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
               ar, norm, small_fork):
         """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D].
-        ref may be a callable (evaluated beside value_proj when small_fork is a _Fork: the few-row projections of the
-        frame-token path run as a parallel branch next to the large value projection)."""
+        ref: the reference points, or (W, b) of the Linear whose sigmoid gives them (evaluated beside value_proj when
+        small_fork is a _Fork: the few-row projections of the frame-token path run as a parallel branch next to the large
+        value projection)."""
         A = ar.alloc
         m1 = ar.mark()
         proj = A(q_rows, 384)
+        if few(q_rows, "msda") and q_pos_shared and norm:
+            # a few dozen queries: offsets|weights (+ the reference points' Linear + sigmoid) in one launch
+            ref_t = ref
+            segs = [(w[pre + "offaw.weight"], w[pre + "offaw.bias"], proj, 384, 384, True, ops.FR_NONE)]
+            if isinstance(ref, tuple):
+                ref_t = A(q_rows, 2)
+                segs.append((ref[0], ref[1], ref_t, 2, 2, False, ops.FR_SIGMOID))
+            fk_s = small_fork if small_fork is not None else _Fork(None)
+            with fk_s:
+                FR(query, q_rows, D, segs, a2=q_pos, lda2=D, a2_rows=q_per_frame)
+            value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
+            fk_s.join()
+            samp = ops.msda_fused(value, proj, ref_t, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
+                                  out=A(q_rows, D))
+            FR(samp, q_rows, D, [(w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, D, D, False, ops.FR_NONE)],
+               res=resid, ldres=D)
+            ln_(resid, norm)
+            ar.release(m1)
+            return
+        if isinstance(ref, tuple):
+            ref_lin = ref
+
+            def ref():
+                r = _lin(A, query, q_rows, D, ref_lin[0], ref_lin[1], 2)
+                return ops.sigmoid(r, out=A(q_rows, 2))
 
         def offaw():
             if q_pos_shared:  # position map shared by all frames: frame-batched launch, stride 0 on the addend
@@ -320,8 +371,10 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                         a2=q_pos, lda2=D)
         if small_fork is not None:
             with small_fork:
-                ref = ref()
+                ref = ref() if callable(ref) else ref
                 offaw()
+        elif callable(ref):
+            ref = ref()
         value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
         if small_fork is not None:
             small_fork.join()
@@ -337,6 +390,18 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     res=resid, ldres=D, res_mode=RES_ADD)
         ar.release(m1)
 
+    taps = {} if os.environ.get("TCE_TAPS") == "1" else None  # bisect aid: copies of intermediates ride out with the outputs
+
+    tap_pool = A(cfg.enc_layers * (16 * T * max(Fk, 1) * D + 3 * T * S * D)) if taps is not None else None  # persistent (base level)
+    tap_off = [0]
+
+    def tap(name, t):
+        if taps is not None:
+            n = t.numel()
+            buf = tap_pool[tap_off[0]:tap_off[0] + n]
+            tap_off[0] += n
+            taps[name] = ops.tile(t.reshape(-1), 1, out=buf).view(t.shape)
+
     for i in range(cfg.enc_layers):
         lp = f"transformer.encoder.layers.{i}."
         if Fk > 0:
@@ -345,35 +410,57 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             # The token path is ~16 launches on T*F (= 40) rows, each a kernel boundary long and on the critical path
             # between two encoder layers: independent ones run as parallel graph branches (tok_stream).
             # (1) tokens gather from their frame by MSDA (:447-454); reference points / offsets beside value_proj
-            def token_ref():
-                r = _lin(A, token, T * Fk, D, w[fp + "reference_points.weight"], w[fp + "reference_points.bias"], 2)
-                return ops.sigmoid(r, out=A(T * Fk, 2))
-            msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, token_ref, 2, True, token,
-                 norm=fp + "norm1", small_fork=_Fork(tok_stream))
+            token_ref = (w[fp + "reference_points.weight"], w[fp + "reference_points.bias"])
+            if "ftf_tok" not in ABLATE:
+                msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, token_ref, 2, True, token,
+                     norm=fp + "norm1", small_fork=_Fork(tok_stream))
+            tap(f"L{i}.token1", token)
             # (2) all T*F tokens attend to each other (:463-469)
             with model.arith("encoder.ftf"):
-                pre = fp + "token_self_atten."
-                qk = A(T * Fk, 2 * D)
-                fk_v = _Fork(tok_stream)
-                with fk_v:
-                    v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
-                gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
-                        batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
-                fk_v.join()
-                att = A(T * Fk, D)
-                ops.mha_core(qk, qk[:, D:], v, 1, NH, T * Fk, T * Fk, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
-                gemm_ex(att, w[pre + "out_proj.weight"], token, T * Fk, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
-                        res=token, ldres=D, res_mode=RES_ADD)
-                ln_(token, fp + "norm2")
+                R = T * Fk
+                if "ftf_tok" not in ABLATE:
+                    pre = fp + "token_self_atten."
+                    qk = A(R, 2 * D)
+                    if few(R, "ftf2"):  # q|k (token + position) and v in one launch
+                        v = A(R, D)
+                        FR(token, R, D, [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
+                                         (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=tpos, lda2=D, a2_rows=Fk)
+                    else:
+                        fk_v = _Fork(tok_stream)
+                        with fk_v:
+                            v = _lin(A, token, R, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                        gemm_ex(token, w[pre + "qk.w"], qk, Fk, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=tpos, lda2=D,
+                                batch=T, sA=Fk * D, sA2=0, sC=Fk * 2 * D)
+                        fk_v.join()
+                    att = A(R, D)
+                    tap(f"L{i}.qk2", qk)
+                    tap(f"L{i}.v2", v)
+                    ops.mha_core(qk, qk[:, D:], v, 1, NH, R, R, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+                    tap(f"L{i}.att2", att)
+                    if few(R, "ftf2"):
+                        FR(att, R, D, [(w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], token, D, D, False, ops.FR_NONE)],
+                           res=token, ldres=D)
+                    else:
+                        gemm_ex(att, w[pre + "out_proj.weight"], token, R, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
+                                res=token, ldres=D, res_mode=RES_ADD)
+                    ln_(token, fp + "norm2")
+                tap(f"L{i}.token2", token)
                 # (3) every pixel attends to the F tokens of its own frame (:480-484)
                 pre = fp + "frame_token_atten."
-                k = A(T * Fk, D)
-                fk_v = _Fork(tok_stream)
-                with fk_v:
-                    v = _lin(A, token, T * Fk, D, w[pre + "v.w"], w[pre + "v.b"], D)
-                gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
-                        sA=Fk * D, sA2=0, sC=Fk * D)
-                fk_v.join()
+                k = A(R, D)
+                if few(R, "ftf3"):
+                    v = A(R, D)
+                    FR(token, R, D, [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, ops.FR_NONE),
+                                     (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=tpos, lda2=D, a2_rows=Fk)
+                else:
+                    fk_v = _Fork(tok_stream)
+                    with fk_v:
+                        v = _lin(A, token, R, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                    gemm_ex(token, w[pre + "k.w"], k, Fk, D, D, D, D, D, bias=w[pre + "k.b"], a2=tpos, lda2=D, batch=T,
+                            sA=Fk * D, sA2=0, sC=Fk * D)
+                    fk_v.join()
+            tap(f"L{i}.k3", k)
+            tap(f"L{i}.v3", v)
             with model.arith("encoder.ftf_x"):
                 if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
                     # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
@@ -391,10 +478,14 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
                                  w[fp + "norm3.bias"])
             ar.release(m0)
+            tap(f"L{i}.src3", src)
             # (4) FFN over all pixels (:489-491)
             ffn(src, T * S, fp, norm=fp + "norm4")
-        msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1")
+            tap(f"L{i}.src4", src)
+        if "enc_msda" not in ABLATE:
+            msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1")
         ffn(src, T * S, lp, norm=lp + "norm2")
+        tap(f"L{i}.src6", src)
         if ar2 is not None and stream2 is not None and lat1_when == f"enc{i}":
             lat1 = start_lat1()
     memory = src
@@ -414,33 +505,47 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         init_ref = ops.tile(ops.sigmoid(r, out=A(Q, 2)), T, out=A(T * Q, 2))
         tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
         ref, ref_dim = init_ref, 2
-        for lid in range(nl):
+        for lid in range(0 if "decoder" not in ABLATE else nl, nl):
             lp = f"transformer.decoder.layers.{lid}."
             m0 = dar.mark()
             pre = lp + "self_attn."
             qk = A(T * Q, 2 * D)
-            gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
-                    sA=Q * D, sA2=0, sC=Q * 2 * D)
-            v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
+            if few(T * Q, "dec"):
+                v = A(T * Q, D)
+                FR(tgt, T * Q, D, [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
+                                   (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=qpos, lda2=D, a2_rows=Q)
+            else:
+                gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
+                        sA=Q * D, sA2=0, sC=Q * 2 * D)
+                v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(T * Q, D)
             if cfg.qtrans:
                 # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
                 ops.mha_core(qk, qk[:, D:], v, Q, NH, T, T, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att, Q * D, D)
             else:
                 ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
-            gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
-                    ldres=D, res_mode=RES_ADD)
+            if few(T * Q, "dec"):
+                FR(att, T * Q, D, [(w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, D, D, False, ops.FR_NONE)],
+                   res=tgt, ldres=D)
+            else:
+                gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                        ldres=D, res_mode=RES_ADD)
             ln_(tgt, lp + "norm2")
             msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar, norm=lp + "norm1",
                  group="decoder")
             ffn(tgt, T * Q, lp, ar=dar, norm=lp + "norm3", group="decoder")
             if cfg.with_box_refine:
                 bp = f"bbox_embed.{lid}.layers."
-                t1 = A(T * Q, D)
-                gemm_ex(tgt, w[bp + "0.weight"], t1, T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
-                t2 = A(T * Q, D)
-                gemm_ex(t1, w[bp + "1.weight"], t2, T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
-                t3 = _lin(A, t2, T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
+                t1, t2 = A(T * Q, D), A(T * Q, D)
+                if few(T * Q, "dec"):
+                    t3 = A(T * Q, 4)
+                    FR(tgt, T * Q, D, [(w[bp + "0.weight"], w[bp + "0.bias"], t1, D, D, False, ops.FR_RELU)])
+                    FR(t1, T * Q, D, [(w[bp + "1.weight"], w[bp + "1.bias"], t2, D, D, False, ops.FR_RELU)])
+                    FR(t2, T * Q, D, [(w[bp + "2.weight"], w[bp + "2.bias"], t3, 4, 4, False, ops.FR_NONE)])
+                else:
+                    gemm_ex(tgt, w[bp + "0.weight"], t1, T * Q, D, D, D, D, D, bias=w[bp + "0.bias"], act=ACT_RELU)
+                    gemm_ex(t1, w[bp + "1.weight"], t2, T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
+                    t3 = _lin(A, t2, T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
                 ops.box_refine(t3, ref, out=inter_ref[lid])
                 ref, ref_dim = inter_ref[lid], 4
             dar.release(m0)
@@ -476,12 +581,19 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         # ride in the decoder branch instead of the main chain's tail
         dA = dar.alloc
         c1 = dA(nl * T * Q, D)
-        gemm_ex(hs, w["controller.layers.0.weight"], c1, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.0.bias"],
-                act=ACT_RELU)
         c2 = dA(nl * T * Q, D)
-        gemm_ex(c1, w["controller.layers.1.weight"], c2, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.1.bias"],
-                act=ACT_RELU)
-        params = _lin(dA, c2, nl * T * Q, D, w["controller.layers.2.weight"], w["controller.layers.2.bias"], npar)
+        if few(nl * T * Q, "dec"):
+            params = dA(nl * T * Q, npar)
+            FR(hs, nl * T * Q, D, [(w["controller.layers.0.weight"], w["controller.layers.0.bias"], c1, D, D, False, ops.FR_RELU)])
+            FR(c1, nl * T * Q, D, [(w["controller.layers.1.weight"], w["controller.layers.1.bias"], c2, D, D, False, ops.FR_RELU)])
+            FR(c2, nl * T * Q, D, [(w["controller.layers.2.weight"], w["controller.layers.2.bias"], params, npar, npar, False,
+                                    ops.FR_NONE)])
+        else:
+            gemm_ex(hs, w["controller.layers.0.weight"], c1, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.0.bias"],
+                    act=ACT_RELU)
+            gemm_ex(c1, w["controller.layers.1.weight"], c2, nl * T * Q, D, D, D, D, D, bias=w["controller.layers.1.bias"],
+                    act=ACT_RELU)
+            params = _lin(dA, c2, nl * T * Q, D, w["controller.layers.2.weight"], w["controller.layers.2.bias"], npar)
         w0f = dA(T, nl * Q * 8, cfg.mask_dim)
         tail = dA(nl, T * Q, 112)
         ops.mask_pack(params, nl, T, Q, cfg.mask_dim, w0f, tail)
@@ -517,6 +629,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     if not model.training:
         out["reference_points"] = keep(mask_refs[-2].reshape(1, T, Q, ref_ld)[..., :2])
     out["memory"] = keep(memory.reshape(T, S, D))
+    if taps:
+        out["taps"] = [{k_: keep(v_) for k_, v_ in taps.items()}]
     ar.release(m0)
     return out
 
@@ -547,7 +661,7 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
             H2, W2 = sizes[i + 1]
             x_next = A(T * H2 * W2, 2 * C)
         hid = int(C * cfg.mlp_ratio)
-        for j in range(depth):
+        for j in range(depth if f"swin{i}" not in ABLATE else 0):
             p = f"{b}layers.{i}.blocks.{j}."
             m0 = ar.mark()
             xn = A(ntok, C)

@@ -38,7 +38,9 @@ class TextPlan:
             self.layers.append((wqkv, bqkv, p))
 
     def forward(self, ids, A):
-        """ids int64 [1, L] on the GPU; A = arena allocator.  Returns (last_hidden_state [L,C], pooler_output [C])."""
+        """ids int64 [1, L] on the GPU; A = arena allocator.  Returns (last_hidden_state [L,C], pooler_output [C]).
+        (The few-row kernel of csrc/fewrow.hip was tried for the dense layers and is slower at K = 768 / 3072 than the
+        split-K GEMM: 12.7 vs 9.8 us, profiles/r03_fewrow.txt.)"""
         sd, C, L = self.sd, self.C, ids.shape[1]
         s = ops._stream()
         x = A(L, C)

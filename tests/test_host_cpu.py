@@ -133,3 +133,8 @@ def test_nested_tensor_from_videos_list():
     nt = nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6), torch.ones(3, 3, 5, 5)])
     assert tuple(nt.tensors.shape) == (2, 3, 3, 5, 6) and tuple(nt.mask.shape) == (2, 3, 5, 6)
     assert not nt.mask[0, :2, :4, :6].any() and nt.mask[0, 2].all() and nt.mask[1, :, :, 5].all()
+    # host shape metadata: padded / un-padded is known without reading the mask back from the device
+    assert nt.unpadded is False and nt.to("cpu").unpadded is False
+    one = nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6)])
+    assert one.unpadded is True and not one.mask.any()
+    assert nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6)], size_divisibility=4).unpadded is False

@@ -334,7 +334,8 @@ def test_msda_reference_op_generic_shapes(ops, N, Lq, M, Dh, L, P):
     close(out, ref, 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("N,Lq,ref_dim", [(2, 300, 2), (3, 5, 4), (1, 8, 2)])
+@pytest.mark.parametrize("N,Lq,ref_dim", [(2, 300, 2), (3, 5, 4), (1, 8, 2),   # <= 8192 items: one wave per item (few-query form)
+                                          (2, 700, 2), (1, 1500, 4)])          # more: 8 lanes per item
 def test_msda_fused(ops, N, Lq, ref_dim):
     g = torch.Generator().manual_seed(Lq)
     M, L, P = 8, 4, 4
@@ -1024,3 +1025,44 @@ def test_rowlin_cold_operands(ops, M, N, K, variant):
         err = (out.double() - ref).abs().amax(dim=1)
         bad = int((~(err < 1e-4 * max(1.0, ref.abs().max().item()))).sum())   # a mis-ordered load gives O(0.1 .. 1)
         assert bad == 0, f"launch {rep}: {bad} of {M} rows wrong (max err {err.nan_to_num(1e30).max().item():.3e})"
+
+
+@pytest.mark.parametrize("R,K", [(40, 256), (25, 256), (1, 256), (64, 256), (200, 256), (32, 768), (7, 96)])
+def test_fewrow_linear(ops, R, K):
+    """tce_fewrow_linear_f32 (exact fp32): three projections of the same rows in one launch (position map on two of them,
+    ReLU / sigmoid), and the LayerNorm epilogue finished by the last workgroup -- in place on the residual, repeated
+    launches on the same counter words, ragged slabs (N = 2, 384, 300)."""
+    g = torch.Generator().manual_seed(R * 7 + K)
+    x = torch.randn(R, K, generator=g)
+    pos = torch.randn(8, K, generator=g)              # shared by groups of 8 rows (the frame's tokens)
+    w1, b1 = torch.randn(384, K, generator=g) / math.sqrt(K), torch.randn(384, generator=g) * 0.2
+    w2, b2 = torch.randn(2, K, generator=g) / math.sqrt(K), torch.randn(2, generator=g) * 0.2
+    w3 = torch.randn(300, K, generator=g) / math.sqrt(K)
+    dx, dpos = dev(x), dev(pos)
+    o1, o2, o3 = (torch.full((R, n), float("nan"), device="cuda") for n in (384, 2, 300))
+    ops.fewrow_linear(dx, R, K, [(dev(w1), dev(b1), o1, 384, 384, True, ops.FR_NONE),
+                                 (dev(w2), dev(b2), o2, 2, 2, False, ops.FR_SIGMOID),
+                                 (dev(w3), None, o3, 300, 300, True, ops.FR_RELU)], a2=dpos, lda2=K, a2_rows=8)
+    xp = x + pos[torch.arange(R) % 8]
+    close(o1, F.linear(xp, w1, b1), 2e-5, 2e-5)
+    close(o2, torch.sigmoid(F.linear(x, w2, b2)), 2e-5, 2e-5)
+    close(o3, F.relu(F.linear(xp, w3)), 2e-5, 2e-5)
+    # out_proj + residual + LayerNorm, in place on the residual stream, three times on the same counter words
+    for N in (256, 300):
+        wo, bo = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g) * 0.2
+        gam, bet = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+        tok = torch.randn(R, N, generator=g)
+        dtok = dev(tok)
+        ref = tok
+        cnt = ops.FewRowCounters("cuda", 16)
+        dwo, dbo, dg, dbt = dev(wo), dev(bo), dev(gam), dev(bet)
+        for rep in range(3):
+            cnt.reset()
+            ops.fewrow_linear(dx, R, K, [(dwo, dbo, dtok, N, N, False, ops.FR_NONE)], res=dtok, ldres=N, ln=(dg, dbt),
+                              counters=cnt)
+            ref = F.layer_norm(ref + F.linear(x, wo, bo), (N,), gam, bet, 1e-5)
+            close(dtok, ref, 5e-5, 5e-5)
+        assert int(cnt.buf.abs().sum()) == 0   # every launch leaves its counter words zero
+    from tce_rvos_amd._lib import TceError
+    with pytest.raises(TceError):   # an output on top of the rows other workgroups still read
+        ops.fewrow_linear(dx, R, K, [(dev(torch.randn(K, K)), None, dx, K, K, False, ops.FR_NONE)])
