@@ -55,6 +55,12 @@ int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
  * run as one batched launch into workspace[splits*M*N], then one pass sums them and applies bias/act/res.  Un-batched
  * GEMMs and (split-fp16 mode) implicit-GEMM convolutions; K % (splits*32) == 0, N % 4 == 0. */
 int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspace, tceStream stream);
+/* The same with the LayerNorm of a post-norm block folded into the reduction pass: C = LayerNorm(A W^T + bias (+ res)) * gamma
+ * + beta (act 0, res_mode 0 or 1, N <= 1024, 16-byte aligned rows).  RoBERTa's attention.output / output sub-layers
+ * (transformers' RobertaSelfOutput / RobertaOutput: dense -> dropout -> LayerNorm(hidden + input)), the decoder FFN's
+ * linear2 + norm3 (tce_deformable_transformer.py:548-552). */
+int tce_gemm_splitk_ln_f32(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma, const float* beta,
+                           float eps, tceStream stream);
 /* which output tile tce_gemm_f32 will use: 128128, 12864 or 6464 (BM*1000-ish code) -- for profiling reports */
 int tce_gemm_select_tile(int32_t M, int32_t N, int32_t batch);
 int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t conv);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "tce_last_error": (C.c_char_p, []),
     "tce_gemm_f32": (i32, [C.POINTER(GemmArgs), c_f]),
     "tce_gemm_splitk_f32": (i32, [C.POINTER(GemmArgs), i32, c_f, c_f]),
+    "tce_gemm_splitk_ln_f32": (i32, [C.POINTER(GemmArgs), i32, c_f, c_f, c_f, f32, c_f]),
     "tce_gemm_select_tile": (i32, [i32, i32, i32]),
     "tce_gemm_select_tile_ex": (i32, [i32, i32, i32, i32, i32]),
     "tce_set_gemm_mode": (i32, [i32]),

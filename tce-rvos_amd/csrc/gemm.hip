@@ -356,9 +356,81 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     C[(long long)m * ldc + n + c] = x;
   }
 }
+// The same reduction with the LayerNorm that follows it in every post-norm block (RoBERTa's attention.output / output
+// sub-layers, the decoder's FFN): one wavefront per output row (N <= 1024) sums the splits, adds bias + residual and
+// normalises the row -- the LayerNorm launch behind a split-K GEMM disappears (24 per clip in the text encoder alone).
+__global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ C,
+                                                               const int M, const int N, const int splits, const int ldc,
+                                                               const int ldres, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long plane = (long long)M * N;
+  const int n4 = N >> 2;  // float4 per row, <= 256: lane takes pieces lane, lane + 64, ...
+  f32x4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = lane + 64 * j;
+    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < n4) {
+      const float* p = ws + (long long)m * N + 4 * q;
+      f32x4 a = *reinterpret_cast<const f32x4*>(p);
+      for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(p + s * plane);
+      if (bias) a += *reinterpret_cast<const f32x4*>(bias + 4 * q);
+      if (res) a += *reinterpret_cast<const f32x4*>(res + (long long)m * ldres + 4 * q);
+      v[j] = a;
+      sum += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)N;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < n4)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = v[j][c] - mean;
+        sq = fmaf(d, d, sq);
+      }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)N + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = lane + 64 * j;
+    if (q < n4) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * q), b = *reinterpret_cast<const f32x4*>(beta + 4 * q);
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = (v[j][c] - mean) * rstd * g[c] + b[c];
+      *reinterpret_cast<f32x4*>(C + (long long)m * ldc + 4 * q) = o;
+    }
+  }
+}
 }  // namespace
 
+static int splitk_impl(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma, const float* beta, float eps,
+                       tceStream stream);
+
 extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspace, tceStream stream) {
+  return splitk_impl(args, splits, workspace, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int tce_gemm_splitk_ln_f32(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma,
+                                      const float* beta, float eps, tceStream stream) {
+  TCE_CHECK_ARG(args && gamma && beta, "tce_gemm_splitk_ln_f32: null pointer");
+  TCE_CHECK_ARG(args->act == 0 && args->res_mode != 2 && args->N <= 1024 && args->N % 4 == 0 && !args->conv,
+                "tce_gemm_splitk_ln_f32: plain GEMM, no activation, additive residual, N <= 1024");
+  TCE_CHECK_ARG(args->ldc % 4 == 0 && (args->res_mode == 0 || args->ldres % 4 == 0) && tce_aligned16(args->C) &&
+                    tce_aligned16(gamma) && tce_aligned16(beta) && (!args->bias || tce_aligned16(args->bias)) &&
+                    (args->res_mode == 0 || tce_aligned16(args->res)),
+                "tce_gemm_splitk_ln_f32: C / res / bias / gamma / beta must be 16-byte aligned with pitches of 4 floats");
+  return splitk_impl(args, splits, workspace, gamma, beta, eps, stream);
+}
+
+static int splitk_impl(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma, const float* beta, float eps,
+                       tceStream stream) {
   TCE_CHECK_ARG(args != nullptr && workspace != nullptr, "tce_gemm_splitk_f32: null args/workspace");
   tceGemmArgs a = *args;
   TCE_CHECK_ARG(splits >= 1 && splits <= 64, "tce_gemm_splitk_f32: splits=%d out of range", splits);
@@ -380,8 +452,12 @@ extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, floa
   const int st = tce_gemm_f32(&g, stream);
   if (st != TCE_OK) return st;
   const long long total = (long long)a.M * (a.N / 4);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
-                     a.res, a.C, a.M, a.N, splits, a.ldc, a.ldres, a.act, a.res_mode);
+  if (gamma)
+    hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(tce_cdiv(a.M, 4)), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
+                       a.res_mode == 1 ? a.res : nullptr, a.C, a.M, a.N, splits, a.ldc, a.ldres, gamma, beta, eps);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
+                       a.res, a.C, a.M, a.N, splits, a.ldc, a.ldres, a.act, a.res_mode);
   TCE_CHECK_LAUNCH("tce_gemm_splitk_f32(reduce)");
   return TCE_OK;
 }

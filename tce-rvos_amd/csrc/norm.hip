@@ -407,9 +407,9 @@ __global__ void __launch_bounds__(256) groupnorm_stats_rows_kernel(const float* 
   }
 }
 
-// merges the nsplit partial (count, mean, M2) triples of a (frame, group) with Chan's formula -> (mean, rstd).
-// One wave per (frame, group): lanes take partials lane, lane + 64, ... (their loads are independent L2 round trips: a
-// serial walk over ~100 partials would cost more than the statistics pass), then a 6-step butterfly merges the lanes.
+// merges partial (count, mean, M2) triples of a (frame, group) with Chan's formula (lanes take partials lane, lane + 16, ...:
+// independent L2 round trips -- a serial walk over ~100 partials would cost more than the statistics pass -- then a
+// butterfly merges the lanes)
 __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, const float nb, const float mb, const float m2b) {
   const float nt = n + nb;
   if (nt > 0.f) {
@@ -419,36 +419,55 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, con
   }
   n = nt;
 }
-__global__ void __launch_bounds__(64) groupnorm_finalize_kernel(const float* __restrict__ ws, float* __restrict__ fin,
-                                                                const int nsplit, const float eps) {
-  const int tg = blockIdx.x, lane = threadIdx.x;
-  const float* p = ws + (long long)tg * nsplit * 3;
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int i = lane; i < nsplit; i += 64) chan_merge(n, mean, m2, p[3 * i], p[3 * i + 1], p[3 * i + 2]);
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
-    chan_merge(n, mean, m2, nb, mb, m2b);
-  }
-  if (lane == 0) {
-    fin[2 * tg] = mean;
-    fin[2 * tg + 1] = rsqrtf(m2 / n + eps);
-  }
-}
-
+// Applies the normalisation.  The merge of the per-chunk partials ("finalize") is done HERE, by every workgroup for its
+// frame's G groups (16 lanes per group: a lane's partials are independent loads, then a 4-step butterfly of Chan's
+// formula): G * nsplit * 12 bytes from L2 per workgroup instead of a separate 5 us launch on the pixel decoder's critical
+// path (12 per clip).
 __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ fin,
+                                                              const float* __restrict__ ws,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                              int HW, int C, int G, int relu, int rows_per_block) {
+                                                              int HW, int C, int G, int relu, int rows_per_block,
+                                                              int nsplit, float eps) {
   extern __shared__ float sm[];  // scale[C], shift[C]
+  __shared__ float sMean[64], sRstd[64];
   float* scale = sm;
   float* shift = sm + C;
   const int t = blockIdx.y;
   const int cg = C / G;
+  {
+    const int l16 = threadIdx.x & 15;
+    for (int g = threadIdx.x >> 4; g < G; g += 16) {
+      const float* p = ws + (long long)(t * G + g) * nsplit * 3;
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int i0 = l16; i0 < nsplit; i0 += 64) {  // four independent partials per step
+        float pn[4], pm[4], p2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 16 * u;
+          const bool ok = i < nsplit;
+          pn[u] = ok ? p[3 * i] : 0.f;
+          pm[u] = ok ? p[3 * i + 1] : 0.f;
+          p2[u] = ok ? p[3 * i + 2] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_merge(n, mean, m2, pn[u], pm[u], p2[u]);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+        chan_merge(n, mean, m2, nb, mb, m2b);
+      }
+      if (l16 == 0) {
+        sMean[g] = mean;
+        sRstd[g] = rsqrtf(m2 / n + eps);
+      }
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cg;
-    const float mean = fin[2 * (t * G + g)], rstd = fin[2 * (t * G + g) + 1];
+    const float mean = sMean[g], rstd = sRstd[g];
     const float sc = rstd * gamma[c];
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
@@ -547,10 +566,9 @@ extern "C" int tce_groupnorm_nsplit(int32_t HW) { return tce_cdiv(HW, groupnorm_
 extern "C" int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
                                  int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream) {
   TCE_CHECK_ARG(x && gamma && beta && out && ws, "tce_groupnorm_f32: null pointer");
-  TCE_CHECK_ARG(T > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C % 4 == 0, "tce_groupnorm_f32: bad shape");
+  TCE_CHECK_ARG(T > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0, "tce_groupnorm_f32: bad shape (G <= 64)");
   TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out), "tce_groupnorm_f32: x/out must be 16-byte aligned");
   const int rows_per = groupnorm_rows_per(HW), nsplit = tce_cdiv(HW, rows_per);
-  float* fin = ws + (long long)T * G * nsplit * 3;
   hipStream_t s = (hipStream_t)stream;
   if (C == 256 && (G == 8 || G == 16 || G == 32 || G == 64)) {
     const dim3 grid(nsplit, T);
@@ -560,10 +578,10 @@ extern "C" int tce_groupnorm_f32(const float* x, const float* gamma, const float
   } else {
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(T * G, nsplit), dim3(256), 0, s, x, ws, HW, C, G, nsplit);
   }
-  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(T * G), dim3(64), 0, s, ws, fin, nsplit, eps);
   const int rows_per_block = 64;
+  // the apply kernel merges the partials itself (no separate finalize launch)
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(tce_cdiv(HW, rows_per_block), T), dim3(256),
-                     (size_t)2 * C * sizeof(float), s, x, fin, gamma, beta, out, HW, C, G, relu, rows_per_block);
+                     (size_t)2 * C * sizeof(float), s, x, ws, gamma, beta, out, HW, C, G, relu, rows_per_block, nsplit, eps);
   TCE_CHECK_LAUNCH("tce_groupnorm_f32");
   return TCE_OK;
 }

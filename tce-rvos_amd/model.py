@@ -104,16 +104,17 @@ ARITH_GROUPS = ("text", "backbone.attn", "backbone.mlp", "backbone.merge", "inpu
 ARITH_POLICIES = {
     "uniform": {},
     "all_f16": {g: "f16" for g in ARITH_GROUPS},
-    # Read off profiles/r03_arith_sensitivity_cfg5*.txt (Swin-B, T=10, 480x854; default and O(1)-logit weights):
-    # cfg5_mixed -- the groups that carry the time (backbone, encoder FFN / value projections, pixel-decoder convolutions and
-    #   FFNs) in single-pass fp16; text, input projections, frame tokens, decoder, mask head stay fp32-class (they steer the
-    #   dynamic mask weights: the decoder group alone costs IoU 4e-4).  Mask IoU vs the oracle 0.99976 / 0.99984, max |d| /
-    #   max|ref| 2.2e-3, 22.5 ms per clip against 28.2 ms uniform f16x3 and 22.3 ms all-fp16 (IoU 0.99955).
-    # cfg5_tight -- only the groups whose fp16 error stays inside the fp32-class bound |d| <= 5e-5 max|ref| that the f16x3 tests
-    #   use (everything downstream of the decoder's queries is excluded by that bound): the pixel decoder's attention / FFN
-    #   sites and the mask head.  3 % faster than uniform f16x3.
-    "cfg5_mixed": {g: "f16" for g in ("backbone.attn", "backbone.mlp", "encoder.ffn", "encoder.msda", "pixel.conv", "pixel.ffn")},
-    "cfg5_tight": {g: "f16" for g in ("pixel.attn", "pixel.xattn", "pixel.ffn", "mask_head")},
+    # Read off profiles/r03_arith_sensitivity_cfg5*.txt (Swin-B, T=10, 480x854, one group at a time in single-pass fp16, default
+    # and O(1)-logit weights) and checked on a second clip / weight set by bench.py's parity leg (profiles/r03_bench_cfg5_*.json):
+    # cfg5_mixed -- single-pass fp16 in everything DOWNSTREAM of the decoder's queries: the pixel decoder (convolutions,
+    #   attention, text cross-attention, FFNs) and the mask head.  |d| / max|ref| <= 1.5e-4, mask IoU vs the oracle >= 0.99998 on
+    #   both clips: the only mix that is robustly inside the 1e-3 IoU criterion.  5 % faster than uniform f16x3.
+    # cfg5_fast -- additionally the backbone (qkv / proj / window attention / MLPs), the encoder FFNs and value projections:
+    #   22.5 ms against 28.2 ms uniform f16x3, but any fp16 rounding UPSTREAM of the queries perturbs the dynamic mask weights
+    #   by 2e-3 .. 5e-3 of max|ref| and that sits ON the criterion: IoU 0.99976 on the table's clip, 0.99846 on the benchmark's
+    #   (the backbone MLPs alone: 0.99986 / 0.99888) -- like every product in fp16 ("all_f16": 0.99955 / 0.99795).
+    "cfg5_mixed": {g: "f16" for g in ("pixel.conv", "pixel.attn", "pixel.xattn", "pixel.ffn", "mask_head")},
+    "cfg5_fast": {g: "f16" for g in ("backbone.attn", "backbone.mlp", "encoder.ffn", "encoder.msda", "pixel.conv", "pixel.ffn")},
 }
 
 

@@ -54,11 +54,15 @@ GEMM_PROFILE = None
 HBM_PROFILE = None
 
 
-def _gemm_launch(g, splitk=1, ws=None):
+def _gemm_launch(g, splitk=1, ws=None, ln=None, eps=1e-5):
     def go():
         if splitk > 1:
             if ws is None or ws.numel() < splitk * g.M * g.N:
                 raise ValueError("split-K GEMM needs a workspace of splits*M*N floats")
+            if ln is not None:  # LayerNorm folded into the reduction pass
+                check(lib().tce_gemm_splitk_ln_f32(C.byref(g), splitk, ws.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), eps,
+                                                   _stream()), "tce_gemm_splitk_ln_f32")
+                return
             check(lib().tce_gemm_splitk_f32(C.byref(g), splitk, ws.data_ptr(), _stream()), "tce_gemm_splitk_f32")
         else:
             check(lib().tce_gemm_f32(C.byref(g), _stream()), "tce_gemm_f32")
@@ -641,11 +645,11 @@ def mask_tail(G, tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride
 
 
 def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=ACT_NONE, res=None, ldres=0,
-            res_mode=RES_NONE, batch=1, sA=0, sA2=0, sW=0, sBias=0, sC=0, sRes=0, splitk=1, ws=None):
+            res_mode=RES_NONE, batch=1, sA=0, sA2=0, sW=0, sBias=0, sC=0, sRes=0, splitk=1, ws=None, ln=None, ln_eps=1e-5):
     """Fully explicit form: tensors only provide base pointers (slices / views welcome); all sizes and
     strides (in floats) are given by the caller.  Used by the model for frame-batched launches where the
     addend (a positional map) is shared by all frames (sA2 = 0) or the output is a level slice of [T,S,C]."""
-    if _ROUTES.rowlin and splitk <= 1 and sW == 0 and sBias == 0 and act in (ACT_NONE, ACT_RELU, ACT_GELU):
+    if _ROUTES.rowlin and splitk <= 1 and ln is None and sW == 0 and sBias == 0 and act in (ACT_NONE, ACT_RELU, ACT_GELU):
         pk = _rowlin_route(w, M, N, K, ldw, batch)
         if pk is not None:
             return rowlin(a, pk, out, M, N, K, lda, ldc, bias=bias, a2=a2, lda2=lda2, act=act, res=res, ldres=ldres,
@@ -662,7 +666,14 @@ def gemm_ex(a, w, out, M, N, K, lda, ldw, ldc, bias=None, a2=None, lda2=0, act=A
         g.res, g.ldres = res.data_ptr(), ldres
     g.act, g.res_mode, g.batch = act, res_mode, batch
     g.sA, g.sA2, g.sW, g.sBias, g.sC, g.sRes = sA, sA2, sW, sBias, sC, sRes
-    _gemm_launch(g, splitk, ws)
+    if ln is not None and splitk <= 1:  # ln = the LayerNorm that follows: folded into a split-K reduction, else its own launch
+        if ldc != N or batch != 1:
+            raise ValueError("gemm_ex(ln=...): dense [M, N] output of one problem")
+        _gemm_launch(g, splitk, ws)
+        check(lib().tce_layernorm_f32(out.data_ptr(), None, ln[0].data_ptr(), ln[1].data_ptr(), out.data_ptr(), M, N, ln_eps,
+                                      _stream()), "tce_layernorm_f32")
+        return out
+    _gemm_launch(g, splitk, ws, ln, ln_eps)
     return out
 
 

@@ -202,10 +202,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         gemm_ex(x, w[pre + l1 + ".weight"], hdn, M, ff, D, D, D, ff, bias=w[pre + l1 + ".bias"], act=ACT_RELU)
         sk = ops.splitk_for(M, D, ff)  # the decoder / frame-token FFNs run on a few dozen rows
         gemm_ex(hdn, w[pre + l2 + ".weight"], x, M, D, ff, ff, ff, D, bias=w[pre + l2 + ".bias"], res=x, ldres=D,
-                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None)
+                res_mode=RES_ADD, splitk=sk, ws=A(sk * M * D) if sk > 1 else None,
+                ln=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)  # the norm rides in the split-K reduction
         ar.release(m1)
-        if norm:
-            ln_(x, norm)
 
     # input_proj + early fusion of a level (:258-307) needs that level's backbone map and the text only: with the extra
     # branches of fork3 the two large levels start as soon as their Swin stage is done, beside the later stages (which

@@ -58,15 +58,15 @@ class TextPlan:
         for wqkv, bqkv, p in self.layers:
             gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
             check(lib().tce_mha_small64_f32(qkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s), "tce_mha_small64_f32")
+            # dense + residual + LayerNorm: the norm rides in the split-K reduction pass
             gemm_ex(att, sd[p + "attention.output.dense.weight"], x, L, C, C, C, C, C, bias=sd[p + "attention.output.dense.bias"],
-                    res=x, ldres=C, res_mode=RES_ADD, splitk=sk_out, ws=ws)
-            ops.layernorm(x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], self.eps,
-                          out=x)
+                    res=x, ldres=C, res_mode=RES_ADD, splitk=sk_out, ws=ws, ln_eps=self.eps,
+                    ln=(sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"]))
             gemm_ex(x, sd[p + "intermediate.dense.weight"], hdn, L, self.ff, C, C, C, self.ff,
                     bias=sd[p + "intermediate.dense.bias"], act=ACT_GELU, splitk=sk_f1, ws=ws)
             gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
-                    bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws)
-            ops.layernorm(x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], self.eps, out=x)
+                    bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws, ln_eps=self.eps,
+                    ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]))
         pooled = A(C)
         gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])
         check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), C, s), "tce_tanh_f32")

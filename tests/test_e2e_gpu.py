@@ -569,13 +569,19 @@ def cfg5_oracle(models):
 
 
 @pytest.mark.parametrize("policy,rel_bound,iou_bound", [
-    ("cfg5_mixed", 5e-3, 1 - 1e-3),   # fp16-class relative error (2.2e-3 measured), the north star's IoU criterion
-    ("cfg5_tight", 1e-4, 1 - 1e-4),   # fp32-class: within 2x of the f16x3 tests' 5e-5 bound
-    ("all_f16", 1.5e-2, 1 - 1e-3),    # BASELINE config 5 taken literally: every product one fp16 MFMA (IoU 0.99955 measured)
+    # everything downstream of the decoder's queries in single-pass fp16: robustly inside the north star's criterion
+    ("cfg5_mixed", 2e-4, 1 - 1e-4),
+    # fp16 upstream of the queries too (backbone, encoder): fp16-class error ON the 1e-3 IoU criterion -- 0.99976 on this clip,
+    # 0.99846 on bench.py's (profiles/r03_bench_cfg5_swin_b_fast.json): asserted as what it is, not as a pass of the criterion
+    ("cfg5_fast", 5e-3, 1 - 3e-3),
+    # BASELINE config 5 taken literally, every product one fp16 MFMA: 0.99955 here, 0.99795 on bench.py's clip
+    ("all_f16", 1.5e-2, 1 - 3e-3),
 ])
 def test_config5_mixed_fp16_matches_oracle(cfg5_oracle, policy, rel_bound, iou_bound):
-    """BASELINE config 5 ("fp16 MFMA") at full size in its reduced-precision arithmetic, per-site map
-    from the committed sensitivity table (profiles/r03_arith_sensitivity_cfg5.txt, tools/arith_sensitivity.py)."""
+    """BASELINE config 5 ("fp16 MFMA") at full size in its reduced-precision arithmetic, per-site maps
+    from the committed sensitivity table (profiles/r03_arith_sensitivity_cfg5.txt, tools/arith_sensitivity.py).  Finding: only
+    the sites downstream of the decoder's queries take single-pass fp16 with margin; upstream of them the error class
+    (2e-3 .. 5e-3 of max|ref|) lands on the IoU criterion and the verdict depends on the clip."""
     model, clip, ref = cfg5_oracle
     assert model._stamp is None or not model.arith_policy
     model.set_arith_policy(policy)
@@ -617,7 +623,7 @@ def test_unit_scale_mask_logits_in_mixed_fp16(models):
     rm = ref["pred_masks"]
     assert (rm.abs() < 1e-2).float().mean().item() > 1e-3
     try:
-        for policy in ("cfg5_mixed", "all_f16"):
+        for policy in ("cfg5_mixed", "cfg5_fast", "all_f16"):
             model.set_arith_policy(policy)
             out = model.forward_features(frames.cuda(), hid.cuda(), pooled.cuda(), float(H), float(W))
             torch.cuda.synchronize()
@@ -625,10 +631,9 @@ def test_unit_scale_mask_logits_in_mixed_fp16(models):
             d = (out["pred_masks"].cpu() - rm).abs().max().item()
             print(f"O(1) logits, policy {policy}: IoU {iou:.6f}  max|d| {d:.2e} (max|ref| {rm.abs().max().item():.2f})")
             if policy == "cfg5_mixed":
-                assert iou > 1 - 1e-3          # measured 0.99944
+                assert iou > 1 - 1e-4          # downstream-of-the-queries sites only: fp32-class masks
             else:
-                # every product in single-pass fp16 sits ON the criterion in this regime (measured 0.99899 here, 0.99960 at
-                # config 5): the reason the mixed policy exists.  Asserted: fp16-class error, and no better than the mix.
+                # fp16 upstream of the queries sits ON the criterion in this regime (cfg5_fast 0.99944, all_f16 0.99899 here)
                 assert iou > 1 - 3e-3
     finally:
         model.set_arith_policy({})

@@ -1066,3 +1066,23 @@ def test_fewrow_linear(ops, R, K):
     from tce_rvos_amd._lib import TceError
     with pytest.raises(TceError):   # an output on top of the rows other workgroups still read
         ops.fewrow_linear(dx, R, K, [(dev(torch.randn(K, K)), None, dx, K, K, False, ops.FR_NONE)])
+
+
+@pytest.mark.parametrize("M,N,K,splits,res", [(32, 768, 3072, 16, True), (25, 256, 2048, 8, True), (1, 768, 768, 4, False),
+                                              (40, 1024, 512, 2, True), (32, 768, 768, 1, True)])
+def test_gemm_splitk_with_layernorm(ops, M, N, K, splits, res):
+    """tce_gemm_splitk_ln_f32: the LayerNorm of a post-norm block folded into the split-K reduction pass (in place on the
+    residual stream, as the text encoder and the decoder FFN call it); splits = 1 takes GEMM + LayerNorm launches."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.2
+    x = torch.randn(M, N, generator=g)
+    gam, bet = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    ref = F.layer_norm(F.linear(a, w, b) + (x if res else 0), (N,), gam, bet, 1e-12)
+    dx = dev(x)
+    ws = torch.empty(max(1, splits) * M * N, device="cuda")
+    ops.gemm_ex(dev(a), dev(w), dx, M, N, K, K, K, N, bias=dev(b), res=dx if res else None, ldres=N,
+                res_mode=ops.RES_ADD if res else ops.RES_NONE, splitk=splits, ws=ws if splits > 1 else None,
+                ln=(dev(gam), dev(bet)), ln_eps=1e-12)
+    close(dx, ref, 2e-4, 2e-4)

@@ -1,4 +1,4 @@
-"""Aggregates two rocprofv3 counter passes into profiles/r02_pmc_traffic.json (HBM-side bytes per kernel launch).
+"""Aggregates two rocprofv3 counter passes into profiles/r03_pmc_traffic.json (PMC_OUT overrides the file name) (HBM-side bytes per kernel launch).
 
     TCE_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants
     TCE_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py  (same flags)
@@ -37,7 +37,7 @@ for name in sorted(set(fetch) | set(write)):
 tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out["kernels"].values())
 out["clips"] = clips
 out["hbm_bytes_per_clip_all_kernels"] = tot / clips
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_traffic.json")
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("PMC_OUT", "r03_pmc_traffic.json"))
 json.dump(out, open(dst, "w"), indent=1)
 print(f"total L2 memory-side traffic: {tot / clips / 1e9:.2f} GB per clip over {clips} clips")
 big = sorted(out["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
