@@ -377,8 +377,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(const float* __re
     v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q < n4) {
       const float* p = ws + (long long)m * N + 4 * q;
+      // partial sums in split order (deterministic); four loads in flight per step
       f32x4 a = *reinterpret_cast<const f32x4*>(p);
-      for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(p + s * plane);
+      int s = 1;
+      for (; s + 3 < splits; s += 4) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(p + (long long)s * plane);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(p + (long long)(s + 1) * plane);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(p + (long long)(s + 2) * plane);
+        const f32x4 p3 = *reinterpret_cast<const f32x4*>(p + (long long)(s + 3) * plane);
+        a += p0;
+        a += p1;
+        a += p2;
+        a += p3;
+      }
+      for (; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(p + (long long)s * plane);
       if (bias) a += *reinterpret_cast<const f32x4*>(bias + 4 * q);
       if (res) a += *reinterpret_cast<const f32x4*>(res + (long long)m * ldres + 4 * q);
       v[j] = a;

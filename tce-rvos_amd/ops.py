@@ -188,6 +188,18 @@ def check_weight_range(named_tensors):
                          f"ops.set_gemm_mode('f32') before loading these weights.")
 
 
+def _hbm_timed(name, rows, nbytes, go):
+    """Runs go(); with HBM_PROFILE on, brackets it with events on the launch stream and records its algorithmic bytes."""
+    if HBM_PROFILE is None:
+        go()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    HBM_PROFILE.append((name, rows, float(nbytes), e0, e1))
+
+
 def _chk(t, name):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise TypeError(f"{name}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
@@ -310,8 +322,10 @@ def groupnorm_cl(x, gamma, beta, T, HW, Cn, G, eps=1e-5, relu=False, out=None, w
         ws = alloc(T * G * (nsplit * 3 + 2)) if alloc else torch.empty(T * G * (nsplit * 3 + 2), dtype=torch.float32, device=x.device)
     if out is None:
         out = alloc(T * HW, Cn) if alloc else torch.empty(T * HW, Cn, dtype=torch.float32, device=x.device)
-    check(lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW,
-                                  Cn, G, eps, 1 if relu else 0, _stream()), "tce_groupnorm_f32")
+    # algorithmic bytes: the map read once for the statistics, once for the apply pass, written once
+    _hbm_timed("groupnorm (stats + apply)", T * HW, 3.0 * T * HW * Cn * 4, lambda: check(
+        lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW, Cn, G, eps,
+                                1 if relu else 0, _stream()), "tce_groupnorm_f32"))
     return out
 
 
@@ -347,8 +361,9 @@ def patch_embed(frames, w, b, gamma, beta, eps=1e-5, out=None, alloc=None):
     Hp, Wp = (H + 3) // 4, (W + 3) // 4
     if out is None:
         out = alloc(T * Hp * Wp, Cn) if alloc else torch.empty(T * Hp * Wp, Cn, dtype=torch.float32, device=frames.device)
-    check(lib().tce_patch_embed_f32(frames.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                    out.data_ptr(), T, H, W, Cn, eps, _stream()), "tce_patch_embed_f32")
+    _hbm_timed("patch_embed", T * Hp * Wp, 4.0 * (T * 3 * H * W + T * Hp * Wp * Cn), lambda: check(
+        lib().tce_patch_embed_f32(frames.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                  T, H, W, Cn, eps, _stream()), "tce_patch_embed_f32"))
     return out, Hp, Wp
 
 
@@ -356,8 +371,10 @@ def window_attn(qkv, qkv_bias, table, T, H, W, Cn, nH, shift, out=None, alloc=No
     _chk(qkv, "qkv")
     if out is None:
         out = alloc(T * H * W, Cn) if alloc else torch.empty(T * H * W, Cn, dtype=torch.float32, device=qkv.device)
-    check(lib().tce_window_attn_f32(qkv.data_ptr(), qkv_bias.data_ptr(), table.data_ptr(), out.data_ptr(), T, H, W, Cn,
-                                    nH, shift, _stream()), "tce_window_attn_f32")
+    # algorithmic bytes: qkv in (3C per token) + out (C per token)
+    _hbm_timed("window_attn", T * H * W, 4.0 * T * H * W * 4 * Cn, lambda: check(
+        lib().tce_window_attn_f32(qkv.data_ptr(), qkv_bias.data_ptr(), table.data_ptr(), out.data_ptr(), T, H, W, Cn, nH, shift,
+                                  _stream()), "tce_window_attn_f32"))
     return out
 
 
