@@ -352,13 +352,12 @@ int tce_graph_destroy(void* graph_exec);
 
 /* ---------------------------------------------------------------------------------------------------
  * Few-row linear layers (R of a few dozen rows; csrc/fewrow.hip): up to three projections of the SAME rows in one launch,
- *     out_s[r, n] = act_s( sum_k (x[r,k] (+ a2[r % a2_rows, k] if seg.use_a2)) W_s[n,k] + bias_s[n] ),
- * exact fp32 on the vector ALUs, and for segment 0 optionally  out_0 = LayerNorm(res + out_0) * gamma + beta  finished by
- * the last workgroup to arrive (no second launch, no waiting).  act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf).  a2_rows = 0: the addend
- * has one row per x row.  counter: device uint32 words, one per 32 rows, ZERO before the launch (the kernel leaves them
- * zero); required with gamma / beta.  `out` of a segment must not overlap x (rows are re-read by other workgroups).
- * Replaces the per-token nn.Linear / LayerNorm / sigmoid call sites of the frame-token layer and the text-side key /
- * value projections (tce_deformable_transformer.py:439-484; segmentation.py:366-371; position of reference points :446).
+ *     out_s[r, n] = act_s( sum_k (x[r,k] (+ a2[r % a2_rows, k] if seg.use_a2)) W_s[n,k] + bias_s[n] )  (+ res[r, n] for s = 0),
+ * exact fp32 on the vector ALUs.  act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf).  a2_rows = 0: the addend has one row per x
+ * row.  `out` of a segment must not overlap x (rows are re-read by other workgroups); out_0 may alias res (in place on the
+ * residual stream).
+ * Replaces the per-token nn.Linear / sigmoid call sites of the frame-token layer, the decoder's per-query projections and
+ * the text-side key / value projections (tce_deformable_transformer.py:439-484,665-790; segmentation.py:366-371).
  */
 typedef struct {
   const float* W;    /* [N, K], row pitch ldw (multiple of 4 floats, 16-byte aligned) */
@@ -369,15 +368,11 @@ typedef struct {
   int32_t act;
 } tceFewRowSeg;
 typedef struct {
-  const float* x;  /* [R, K], row pitch ldx */
-  const float* a2; /* optional addend rows, pitch lda2 */
-  const float* res;   /* optional residual of segment 0, pitch ldres */
-  const float* gamma; /* optional LayerNorm of segment 0 (with beta and counter) */
-  const float* beta;
-  uint32_t* counter;
+  const float* x;   /* [R, K], row pitch ldx */
+  const float* a2;  /* optional addend rows, pitch lda2 */
+  const float* res; /* optional residual added to segment 0, pitch ldres */
   int64_t ldx, lda2, ldres;
   int32_t a2_rows, R, K, nseg;
-  float eps;
   tceFewRowSeg seg[3];
 } tceFewRowArgs;
 int tce_fewrow_linear_f32(const tceFewRowArgs* args, tceStream stream);

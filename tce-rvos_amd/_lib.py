@@ -46,9 +46,9 @@ class FewRowSeg(C.Structure):
 
 
 class FewRowArgs(C.Structure):
-    _fields_ = [("x", c_f), ("a2", c_f), ("res", c_f), ("gamma", c_f), ("beta", c_f), ("counter", c_f),
+    _fields_ = [("x", c_f), ("a2", c_f), ("res", c_f),
                 ("ldx", i64), ("lda2", i64), ("ldres", i64),
-                ("a2_rows", i32), ("R", i32), ("K", i32), ("nseg", i32), ("eps", f32), ("seg", FewRowSeg * 3)]
+                ("a2_rows", i32), ("R", i32), ("K", i32), ("nseg", i32), ("seg", FewRowSeg * 3)]
 
 
 class CopySeg(C.Structure):

@@ -6,18 +6,17 @@
 // profiles/r03_ablate_cfg2.txt).
 //
 //   out_s[r, n] = act_s( sum_k (x[r,k] (+ a2[r % a2_rows, k] if the segment asks)) W_s[n,k] + b_s[n] )      s < nseg <= 3
-//   optional, segment 0 only:  out_0 = LayerNorm(res + out_0) * gamma + beta
+//   optional, segment 0 only:  out_0 += res   (the residual stream, in place)
 //
 // Exact fp32 on the vector ALUs (fmaf chains in k order: no operand splitting, no range contract).  One launch serves up to
 // three projections of the SAME rows (q|k with the position map added and v without; reference points through a sigmoid
-// beside the offsets|weights projection).  A workgroup owns an 8-column slab of one segment and up to 64 rows: x rows
-// (+ addend) and the W slab are staged in LDS with full-line loads, thread (column c, row group g) accumulates rows
-// g, g+32 with broadcast reads of x.  More slabs than CUs are never needed here (N <= 1024), so the launch is one
-// wave of workgroups and costs about one memory round trip + R*16*K/256 FMAs per thread.
-// LayerNorm epilogue without a second launch: every slab workgroup of segment 0 writes res + linear to `out`, publishes it
-// (threadfence + one atomic on a per-row-block counter) and the LAST arriver normalises the finished rows (after an
-// agent-scope acquire fence, which invalidates its non-coherent L1) and resets the counter.  No workgroup ever waits for another: legal
-// inside a hipGraph next to anything, deterministic (one workgroup reduces complete rows in a fixed order).
+// beside the offsets|weights projection).  A workgroup owns an 8-column slab of one segment and 32 rows: x rows (+ addend)
+// and the W slab are staged in LDS with full-line loads, thread (column c, row group g) accumulates row g with broadcast
+// reads of x.  More slabs than CUs are never needed here (N <= 1024), so the launch is one wave of workgroups and costs
+// about one memory round trip.
+// NOT here: a LayerNorm epilogue.  It was built (every slab workgroup publishes its rows, the last arriver normalises them)
+// and measured: the agent-scope release / acquire it needs is an L2 write-back + invalidate on this 8-XCD part, 17-50 us --
+// more than the LayerNorm launch it saves (profiles/r03_fewrow.txt); removed.
 #include "common.h"
 #include "../../include/tce_rvos.h"
 
@@ -38,12 +37,8 @@ struct FrArgs {
   const float* x;
   const float* a2;
   const float* res;
-  const float* gamma;
-  const float* beta;
-  unsigned* counter;
   long long ldx, lda2, ldres;
-  int a2_rows, R, K, nseg, ln;
-  float eps;
+  int a2_rows, R, K, nseg;
   FrSegDev seg[3];
 };
 
@@ -57,8 +52,7 @@ template <int RPT>
 __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
   __shared__ __attribute__((aligned(16))) float sX[32 * RPT * FR_PITCH];
   __shared__ __attribute__((aligned(16))) float sW[FR_COLS * FR_PITCH];
-  __shared__ unsigned sLast;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   int s = 0;
   if (p.nseg > 1 && (int)blockIdx.x >= p.seg[1].slab0) s = 1;
   if (p.nseg > 2 && (int)blockIdx.x >= p.seg[2].slab0) s = 2;
@@ -125,7 +119,6 @@ __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
     }
   }
   const int n = n0 + c;
-  const bool with_ln = p.ln && s == 0;
   if (n < sg.N) {
     const float bv = sg.bias ? sg.bias[n] : 0.f;
 #pragma unroll
@@ -141,63 +134,6 @@ __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
       }
     }
   }
-  if (!with_ln) return;
-  // publish the slab; the last arriver of this row block normalises its rows
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned nslabs = (unsigned)((sg.N + FR_COLS - 1) / FR_COLS);
-    const unsigned old = atomicAdd(p.counter + blockIdx.y, 1u);
-    sLast = (old == nslabs - 1) ? 1u : 0u;
-    if (sLast) p.counter[blockIdx.y] = 0u;  // ready for the next launch (stream order separates the launches)
-  }
-  __syncthreads();
-  if (!sLast) return;
-  // acquire at agent scope: invalidates this CU's (non-coherent) L1, so the plain, pipelinable loads below see the other
-  // workgroups' slabs.  (Per-element atomic loads were one dependent L2 round trip per row: 20 us for 40 rows.)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const int N = sg.N;
-  const float invN = 1.0f / (float)N;
-  // a wave normalises rows wave, wave+4, ...; two rows per step so that their loads are in flight together
-  for (int rb = wave; rb < nr; rb += 8) {
-    float v[2][16];  // N <= 1024
-    float sum[2] = {0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = rb + 4 * u;
-      const float* row = sg.out + (long long)(r0 + min(r, nr - 1)) * sg.ldo;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int col = lane + 64 * j;
-        v[u][j] = (col < N) ? row[col] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sum[u] += v[u][j];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = rb + 4 * u;
-      const float mean = wave_sum(sum[u]) * invN;
-      float sq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int col = lane + 64 * j;
-        const float d = col < N ? v[u][j] - mean : 0.f;
-        sq = fmaf(d, d, sq);
-      }
-      const float rstd = rsqrtf(wave_sum(sq) * invN + p.eps);
-      if (r < nr) {
-        float* row = sg.out + (long long)(r0 + r) * sg.ldo;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int col = lane + 64 * j;
-          if (col < N) row[col] = (v[u][j] - mean) * rstd * p.gamma[col] + p.beta[col];
-        }
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -207,10 +143,9 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
   TCE_CHECK_ARG(a->R > 0 && a->K > 0 && a->K % 4 == 0 && a->ldx % 4 == 0 && tce_aligned16(a->x),
                 "tce_fewrow_linear_f32: K and ldx must be multiples of 4, x 16-byte aligned");
   FrArgs p;
-  p.x = a->x; p.a2 = a->a2; p.res = a->res; p.gamma = a->gamma; p.beta = a->beta; p.counter = a->counter;
+  p.x = a->x; p.a2 = a->a2; p.res = a->res;
   p.ldx = a->ldx; p.lda2 = a->lda2; p.ldres = a->ldres;
-  p.a2_rows = a->a2_rows; p.R = a->R; p.K = a->K; p.nseg = a->nseg; p.eps = a->eps;
-  p.ln = (a->gamma != nullptr) ? 1 : 0;
+  p.a2_rows = a->a2_rows; p.R = a->R; p.K = a->K; p.nseg = a->nseg;
   int slabs = 0;
   for (int s = 0; s < 3; ++s) {
     FrSegDev& d = p.seg[s];
@@ -229,11 +164,6 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
     d.W = g.W; d.bias = g.bias; d.out = g.out; d.N = g.N; d.ldw = g.ldw; d.ldo = g.ldo; d.use_a2 = g.use_a2; d.act = g.act;
     d.slab0 = slabs;
     slabs += tce_cdiv(g.N, FR_COLS);
-  }
-  if (p.ln) {
-    TCE_CHECK_ARG(a->beta && a->counter && a->seg[0].N <= 1024, "tce_fewrow_linear_f32: LayerNorm epilogue needs beta, a zeroed "
-                  "counter word per 32 rows and N <= 1024");
-    TCE_CHECK_ARG(a->seg[0].act == 0, "tce_fewrow_linear_f32: LayerNorm epilogue takes no activation");
   }
   TCE_CHECK_ARG(!a->res || a->ldres >= a->seg[0].N, "tce_fewrow_linear_f32: residual pitch");
   hipLaunchKernelGGL(fewrow_linear_kernel<1>, dim3(slabs, tce_cdiv(a->R, 32)), dim3(256), 0, (hipStream_t)stream, p);

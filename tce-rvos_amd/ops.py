@@ -1020,48 +1020,22 @@ def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_m
 
 # ---------------------------------------------------------------------------------------------------------------
 # Few-row linear layers (csrc/fewrow.hip: tce_fewrow_linear_f32): the per-token projections of the frame-token path, the
-# text-side key / value projections -- a few dozen rows, exact fp32, up to three projections of the same rows per launch,
-# LayerNorm epilogue finished by the last workgroup to arrive.
+# decoder's per-query projections, the text-side key / value projections -- a few dozen rows, exact fp32, up to three
+# projections of the same rows per launch.
 # ---------------------------------------------------------------------------------------------------------------
 FEWROW_MAX_ROWS = int(os.environ.get("TCE_FEWROW_MAX_ROWS", 256))
 FR_NONE, FR_RELU, FR_SIGMOID, FR_GELU = 0, 1, 2, 3
 
 
-class FewRowCounters:
-    """Zeroed counter words for the LayerNorm epilogues of one launch program: every launch takes the next words (the same
-    ones on every pass, so graph replay sees stable addresses); launches that may run concurrently never share a word, and
-    every launch leaves its words zero."""
-
-    def __init__(self, device, n=2048):
-        self.buf = torch.zeros(n, dtype=torch.int32, device=device)
-        self.pos = 0
-
-    def reset(self):
-        self.pos = 0
-
-    def take(self, rows):
-        n = (rows + 31) // 32
-        if self.pos + n > self.buf.numel():
-            raise MemoryError("tce_rvos_amd: few-row counter pool exhausted")
-        p = self.buf.data_ptr() + 4 * self.pos
-        self.pos += n
-        return p
-
-
-def fewrow_linear(x, R, K, segs, ldx=None, a2=None, lda2=0, a2_rows=0, res=None, ldres=0, ln=None, eps=1e-5, counters=None):
-    """segs: list of (W [N,K] (row-strided view ok), bias or None, out tensor, N, ldo, use_a2, act).  ln = (gamma, beta):
-    out_0 <- LayerNorm(res + out_0); needs `counters` (a FewRowCounters)."""
+def fewrow_linear(x, R, K, segs, ldx=None, a2=None, lda2=0, a2_rows=0, res=None, ldres=0):
+    """segs: list of (W [N,K] (row-strided view ok), bias or None, out tensor, N, ldo, use_a2, act); res: added to segment 0."""
     from ._lib import FewRowArgs
     q = FewRowArgs()
-    q.x, q.ldx, q.R, q.K, q.nseg, q.eps = x.data_ptr(), (K if ldx is None else ldx), R, K, len(segs), eps
+    q.x, q.ldx, q.R, q.K, q.nseg = x.data_ptr(), (K if ldx is None else ldx), R, K, len(segs)
     if a2 is not None:
         q.a2, q.lda2, q.a2_rows = a2.data_ptr(), lda2, a2_rows
     if res is not None:
         q.res, q.ldres = res.data_ptr(), ldres
-    if ln is not None:
-        if counters is None:
-            raise ValueError("fewrow_linear: the LayerNorm epilogue needs a counter pool")
-        q.gamma, q.beta, q.counter = ln[0].data_ptr(), ln[1].data_ptr(), counters.take(R)
     for i, (W, b, out, N, ldo, use_a2, act) in enumerate(segs):
         sg = q.seg[i]
         sg.W, sg.bias, sg.out = W.data_ptr(), (b.data_ptr() if b is not None else None), out.data_ptr()

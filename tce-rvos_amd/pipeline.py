@@ -109,9 +109,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     Q = cfg.num_queries
     ff = cfg.dim_feedforward
     # Few-row kernel (csrc/fewrow.hip): the per-token / per-query projections (a few dozen rows, K = 256) as exact-fp32 launches
-    # that serve several projections of the same rows at once (TCE_FEWROW=0: tiled GEMMs).  Its LayerNorm epilogue is NOT
-    # used here: finishing the rows in the last workgroup needs an agent-scope release / acquire, which on this 8-XCD part is
-    # an L2 write-back + invalidate -- 19 us, more than the LayerNorm launch it saves (profiles/r03_fewrow.txt).
+    # that serve several projections of the same rows at once (TCE_FEWROW=0: tiled GEMMs).  The LayerNorms stay launches of
+    # their own: finishing rows in "the last workgroup" needs an agent-scope release / acquire, on this 8-XCD part an L2
+    # write-back + invalidate -- 19 us, more than the launch it would save (profiles/r03_fewrow.txt).
     few_ok = os.environ.get("TCE_FEWROW", "1") != "0"
     FR = ops.fewrow_linear
 

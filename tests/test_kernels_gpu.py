@@ -1030,8 +1030,7 @@ def test_rowlin_cold_operands(ops, M, N, K, variant):
 @pytest.mark.parametrize("R,K", [(40, 256), (25, 256), (1, 256), (64, 256), (200, 256), (32, 768), (7, 96)])
 def test_fewrow_linear(ops, R, K):
     """tce_fewrow_linear_f32 (exact fp32): three projections of the same rows in one launch (position map on two of them,
-    ReLU / sigmoid), and the LayerNorm epilogue finished by the last workgroup -- in place on the residual, repeated
-    launches on the same counter words, ragged slabs (N = 2, 384, 300)."""
+    ReLU / sigmoid / GELU), the residual of segment 0 in place, ragged slabs (N = 2, 384, 300), several 32-row passes."""
     g = torch.Generator().manual_seed(R * 7 + K)
     x = torch.randn(R, K, generator=g)
     pos = torch.randn(8, K, generator=g)              # shared by groups of 8 rows (the frame's tokens)
@@ -1047,22 +1046,15 @@ def test_fewrow_linear(ops, R, K):
     close(o1, F.linear(xp, w1, b1), 2e-5, 2e-5)
     close(o2, torch.sigmoid(F.linear(x, w2, b2)), 2e-5, 2e-5)
     close(o3, F.relu(F.linear(xp, w3)), 2e-5, 2e-5)
-    # out_proj + residual + LayerNorm, in place on the residual stream, three times on the same counter words
+    # out_proj + residual in place on the residual stream (x is another tensor), N = 256 and a ragged 300
     for N in (256, 300):
         wo, bo = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g) * 0.2
-        gam, bet = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
         tok = torch.randn(R, N, generator=g)
         dtok = dev(tok)
-        ref = tok
-        cnt = ops.FewRowCounters("cuda", 16)
-        dwo, dbo, dg, dbt = dev(wo), dev(bo), dev(gam), dev(bet)
-        for rep in range(3):
-            cnt.reset()
-            ops.fewrow_linear(dx, R, K, [(dwo, dbo, dtok, N, N, False, ops.FR_NONE)], res=dtok, ldres=N, ln=(dg, dbt),
-                              counters=cnt)
-            ref = F.layer_norm(ref + F.linear(x, wo, bo), (N,), gam, bet, 1e-5)
-            close(dtok, ref, 5e-5, 5e-5)
-        assert int(cnt.buf.abs().sum()) == 0   # every launch leaves its counter words zero
+        ops.fewrow_linear(dx, R, K, [(dev(wo), dev(bo), dtok, N, N, False, ops.FR_GELU if N == 300 else ops.FR_NONE)], res=dtok,
+                          ldres=N)
+        lin = F.linear(x, wo, bo)
+        close(dtok, tok + (F.gelu(lin) if N == 300 else lin), 5e-5, 5e-5)
     from tce_rvos_amd._lib import TceError
     with pytest.raises(TceError):   # an output on top of the rows other workgroups still read
         ops.fewrow_linear(dx, R, K, [(dev(torch.randn(K, K)), None, dx, K, K, False, ops.FR_NONE)])
