@@ -171,10 +171,22 @@ int tce_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_s
 int tce_msda_fused_f32(const float* value, const float* proj, const float* ref, float* out,
                        const int32_t* shapes_hw /* host, [L,2] */, int32_t N, int32_t S, int32_t M, int32_t Lq,
                        int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
+/* The same for a padded clip: valid_hw (host, [L,2]) = rows / columns of each level that are NOT padding (rectangular,
+ * top-left valid region; NULL = un-padded).  Reference points are multiplied per level by the valid ratios (wv/W, hv/H)
+ * (tce_deformable_transformer.py:125-132,180,590-594: get_valid_ratio, reference_points * valid_ratios) and value rows of
+ * padded positions read as zero (ms_deform_attn.py:96-97: value.masked_fill(input_padding_mask, 0)). */
+int tce_msda_fused_valid_f32(const float* value, const float* proj, const float* ref, float* out,
+                             const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M, int32_t Lq,
+                             int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
 
 /* Sine position map of an un-padded [T,h,w] grid, channels-last [T*h*w, 2F] (+ optional per-channel addend,
  * the level embedding).  Reference: position_encoding.py:64-84 (normalize, scale 2*pi, the -0.5 shift). */
 int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, tceStream stream);
+/* The same for a clip padded to a larger size (position_encoding.py:64-84 with a mask): rows >= hv / columns >= wv of the
+ * map are padding (rectangular, top-left valid region: what nested_tensor_from_videos_list produces); the embedding is the
+ * cumulative count of non-padded positions normalised by its last value, as the reference computes it. */
+int tce_pos_sine2d_valid_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, int32_t hv, int32_t wv,
+                             tceStream stream);
 
 /* Resampling on channels-last maps [T,h,w,C]:
  *   nearest  : out[T,ho,wo,C] = in[.., floor(y*h/ho), floor(x*w/wo), :]  (PyTorch legacy 'nearest'), optional "+ add"

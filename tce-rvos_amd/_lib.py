@@ -84,7 +84,10 @@ SIGNATURES = {
     "tce_ms_deform_attn_forward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_ms_deform_attn_backward_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_msda_fused_f32": (i32, [c_f, c_f, c_f, c_f, C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_msda_fused_valid_f32": (i32, [c_f, c_f, c_f, c_f, C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32,
+                                       i32, c_f]),
     "tce_pos_sine2d_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
+    "tce_pos_sine2d_valid_f32": (i32, [c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_bilinear_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_add_f32": (i32, [c_f, c_f, c_f, i64, i64, c_f]),

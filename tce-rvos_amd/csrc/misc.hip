@@ -7,8 +7,10 @@ namespace {
 
 // position_encoding.py:64-84 for an all-valid mask: y_embed = (y+1-0.5)/(h+1e-6)*2pi, channels [pos_y(F) | pos_x(F)],
 // channel i: embed / 10000^(2*(i/2)/F), sin for even i, cos for odd i.
+// Padded clips (rows >= hv / columns >= wv are padding; rectangular masks only): y_embed is the cumulative count of
+// non-padded rows IN THIS COLUMN -- min(y + 1, hv) in a valid column, 0 in a padded one -- normalised by its last value.
 __global__ void __launch_bounds__(256) pos_sine2d_kernel(float* __restrict__ out, const float* __restrict__ add, int T,
-                                                         int h, int w, int F, long long total) {
+                                                         int h, int w, int F, long long total, int hv, int wv) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int C = 2 * F;
@@ -19,8 +21,9 @@ __global__ void __launch_bounds__(256) pos_sine2d_kernel(float* __restrict__ out
   const float two_pi = 6.283185307179586f;
   const bool is_y = c < F;
   const int i = is_y ? c : c - F;
-  const float e = is_y ? ((float)(y + 1) - 0.5f) / ((float)h + 1e-6f) * two_pi
-                       : ((float)(x + 1) - 0.5f) / ((float)w + 1e-6f) * two_pi;
+  const float ye = x < wv ? (float)min(y + 1, hv) : 0.f, yl = x < wv ? (float)hv : 0.f;  // cumsum value here / in the last row
+  const float xe = y < hv ? (float)min(x + 1, wv) : 0.f, xl = y < hv ? (float)wv : 0.f;
+  const float e = is_y ? (ye - 0.5f) / (yl + 1e-6f) * two_pi : (xe - 0.5f) / (xl + 1e-6f) * two_pi;
   const float dim_t = powf(10000.0f, (float)(2 * (i / 2)) / (float)F);
   const float v = e / dim_t;
   float r = (i & 1) ? cosf(v) : sinf(v);
@@ -250,10 +253,16 @@ __global__ void __launch_bounds__(256) copy_segments_kernel(CopySegs segs) {
 
 extern "C" int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F,
                                   tceStream stream) {
-  TCE_CHECK_ARG(out && T > 0 && h > 0 && w > 0 && F > 0, "tce_pos_sine2d_f32: bad arguments");
+  return tce_pos_sine2d_valid_f32(out, add, T, h, w, F, h, w, stream);
+}
+
+extern "C" int tce_pos_sine2d_valid_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, int32_t hv,
+                                        int32_t wv, tceStream stream) {
+  TCE_CHECK_ARG(out && T > 0 && h > 0 && w > 0 && F > 0 && hv >= 1 && hv <= h && wv >= 1 && wv <= w,
+                "tce_pos_sine2d_f32: bad arguments");
   const long long total = (long long)T * h * w * 2 * F;
   hipLaunchKernelGGL(pos_sine2d_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, add, T, h, w,
-                     F, total);
+                     F, total, hv, wv);
   TCE_CHECK_LAUNCH("tce_pos_sine2d_f32");
   return TCE_OK;
 }

@@ -19,12 +19,18 @@ namespace {
 constexpr int D = 32;
 constexpr int MAXL = 8;
 
+// hv / wv: rows / columns of the level that are NOT padding (== H / W for an un-padded clip); vrx / vry = wv / W, hv / H:
+// the reference multiplies reference points by these "valid ratios" per level and zero-fills the value rows of padded
+// positions (tce_deformable_transformer.py:125-132,180; ops/modules/ms_deform_attn.py:96-97).  Rectangular (top-left)
+// valid regions only: what nested_tensor_from_videos_list produces.
 struct LevelInfo {
   int H[MAXL], W[MAXL], start[MAXL];
+  int hv[MAXL], wv[MAXL];
+  float vrx[MAXL], vry[MAXL];
 };
 
 __device__ __forceinline__ float bilinear_gather(const float* __restrict__ vbase, int Hl, int Wl, long long row_stride,
-                                                 float h_im, float w_im) {
+                                                 float h_im, float w_im, int Hv, int Wv) {
   // vbase points at value[n, level_start, m, d]; row_stride = M*D floats between consecutive spatial positions
   float val = 0.f;
   if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
@@ -33,10 +39,11 @@ __device__ __forceinline__ float bilinear_gather(const float* __restrict__ vbase
     const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
     const float hh = 1.f - lh, hw = 1.f - lw;
     float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-    if (h_low >= 0 && w_low >= 0) v1 = vbase[((long long)h_low * Wl + w_low) * row_stride];
-    if (h_low >= 0 && w_high <= Wl - 1) v2 = vbase[((long long)h_low * Wl + w_high) * row_stride];
-    if (h_high <= Hl - 1 && w_low >= 0) v3 = vbase[((long long)h_high * Wl + w_low) * row_stride];
-    if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = vbase[((long long)h_high * Wl + w_high) * row_stride];
+    // corners outside the level contribute nothing; corners on padded positions read a zero-filled value row
+    if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = vbase[((long long)h_low * Wl + w_low) * row_stride];
+    if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = vbase[((long long)h_low * Wl + w_high) * row_stride];
+    if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = vbase[((long long)h_high * Wl + w_low) * row_stride];
+    if (h_high < Hv && w_high < Wv) v4 = vbase[((long long)h_high * Wl + w_high) * row_stride];
     val = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
   }
   return val;
@@ -84,11 +91,11 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const float* __restrict
       pw = row[M * LP * 2 + m * LP + pj];  // logit
       const float* rp = aw_or_ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
       if (ref_dim == 2) {
-        px = rp[0] + ox / (float)lv.W[l];
-        py = rp[1] + oy / (float)lv.H[l];
+        px = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+        py = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
       } else {
-        px = rp[0] + ox / (float)P * rp[2] * 0.5f;
-        py = rp[1] + oy / (float)P * rp[3] * 0.5f;
+        px = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+        py = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
       }
     }
   }
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const float* __restrict
     const int l = j / P;
     const int Hl = lv.H[l], Wl = lv.W[l];
     const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
-    if (active) acc += w * bilinear_gather(vn + (long long)lv.start[l] * row_stride, Hl, Wl, row_stride, h_im, w_im);
+    if (active) acc += w * bilinear_gather(vn + (long long)lv.start[l] * row_stride, Hl, Wl, row_stride, h_im, w_im, lv.hv[l], lv.wv[l]);
   }
   if (active) out[item * D + d] = acc;
 }
@@ -162,11 +169,11 @@ __global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restr
       pw[e] = row[M * LP * 2 + m * LP + pj];  // logit
       const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
       if (ref_dim == 2) {
-        px[e] = rp[0] + ox / (float)lv.W[l];
-        py[e] = rp[1] + oy / (float)lv.H[l];
+        px[e] = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+        py[e] = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
       } else {
-        px[e] = rp[0] + ox / (float)P * rp[2] * 0.5f;
-        py[e] = rp[1] + oy / (float)P * rp[3] * 0.5f;
+        px[e] = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+        py[e] = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
       }
     }
   }
@@ -199,10 +206,11 @@ __global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restr
       const float hh = 1.f - lh, hw = 1.f - lw;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
-      if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
-      if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
-      if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
-      if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+      const int Hv = lv.hv[l], Wv = lv.wv[l];  // rows / columns that are not padding (their value rows read as zero)
+      if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
+      if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
+      if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
+      if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
       const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] += w * (c1 * v1[c] + c2 * v2[c] + c3 * v3[c] + c4 * v4[c]);
@@ -269,11 +277,11 @@ __global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __res
         pw[e] = row[M * LP * 2 + m * LP + pj];  // logit
         const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
         if (ref_dim == 2) {
-          px[e] = rp[0] + ox / (float)lv.W[l];
-          py[e] = rp[1] + oy / (float)lv.H[l];
+          px[e] = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+          py[e] = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
         } else {
-          px[e] = rp[0] + ox / (float)P * rp[2] * 0.5f;
-          py[e] = rp[1] + oy / (float)P * rp[3] * 0.5f;
+          px[e] = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+          py[e] = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
         }
       }
     }
@@ -302,18 +310,19 @@ __global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __res
         const float hh = 1.f - lh, hw = 1.f - lw;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
+        const int Hv = lv.hv[l], Wv = lv.wv[l];  // rows / columns that are not padding (their value rows read as zero)
         if (l >= first_staged) {  // loop-uniform: this level lives in LDS
           const float* lbase = reinterpret_cast<const float*>(smem) + (lv.start[l] - staged_row0) * D + sub * 4;
-          if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_low) * D);
-          if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_high) * D);
-          if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_low) * D);
-          if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_high) * D);
+          if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_low) * D);
+          if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_high) * D);
+          if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_low) * D);
+          if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_high) * D);
         } else {
           const float* vbase = vn + (long long)lv.start[l] * row_stride;
-          if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
-          if (h_low >= 0 && w_high <= Wl - 1) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
-          if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
-          if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+          if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
+          if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
+          if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
+          if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
         }
         const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
 #pragma unroll
@@ -361,7 +370,7 @@ __global__ void __launch_bounds__(256) msda_plain_dev_kernel(const float* __rest
     const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
     const long long st = starts[l];
     const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
-    if (active) acc += w * bilinear_gather(vn + st * row_stride, Hl, Wl, row_stride, h_im, w_im);
+    if (active) acc += w * bilinear_gather(vn + st * row_stride, Hl, Wl, row_stride, h_im, w_im, Hl, Wl);
   }
   if (active) out[item * D + d] = acc;
 }
@@ -454,7 +463,7 @@ __global__ void __launch_bounds__(256) msda_generic_dev_kernel(const float* __re
     for (int pt = 0; pt < P; ++pt) {
       const long long base = item * (L * P) + l * P + pt;
       const float x = loc[base * 2 + 0], y = loc[base * 2 + 1], w = aw[base];
-      acc += w * bilinear_gather(vl, Hl, Wl, row_stride, y * (float)Hl - 0.5f, x * (float)Wl - 0.5f);
+      acc += w * bilinear_gather(vl, Hl, Wl, row_stride, y * (float)Hl - 0.5f, x * (float)Wl - 0.5f, Hl, Wl);
     }
   }
   out[idx] = acc;
@@ -570,11 +579,11 @@ __global__ void __launch_bounds__(256) msda_fused_fewq_kernel(const float* __res
     logit = row[M * LP * 2 + m * LP + pj];
     const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
     if (ref_dim == 2) {
-      px = rp[0] + ox / (float)lv.W[l];
-      py = rp[1] + oy / (float)lv.H[l];
+      px = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+      py = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
     } else {
-      px = rp[0] + ox / (float)P * rp[2] * 0.5f;
-      py = rp[1] + oy / (float)P * rp[3] * 0.5f;
+      px = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+      py = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
     }
   }
   float mx = logit;
@@ -598,8 +607,9 @@ __global__ void __launch_bounds__(256) msda_fused_fewq_kernel(const float* __res
       const float hh = 1.f - lh, hw = 1.f - lw;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       f32x4 v[4][2] = {{z, z}, {z, z}, {z, z}, {z, z}};
-      const bool ok[4] = {h_low >= 0 && w_low >= 0, h_low >= 0 && w_high <= Wl - 1, h_high <= Hl - 1 && w_low >= 0,
-                          h_high <= Hl - 1 && w_high <= Wl - 1};
+      const int Hv = lv.hv[l], Wv = lv.wv[l];
+      const bool ok[4] = {h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv, h_low >= 0 && w_high < Wv && h_low < Hv,
+                          h_high < Hv && w_low >= 0 && w_low < Wv, h_high < Hv && w_high < Wv};
       const long long pos[4] = {(long long)h_low * Wl + w_low, (long long)h_low * Wl + w_high, (long long)h_high * Wl + w_low,
                                 (long long)h_high * Wl + w_high};
 #pragma unroll
@@ -698,6 +708,13 @@ extern "C" int tce_debug_msda_set_fewq(int32_t on) {
 extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const float* ref, float* out,
                                   const int32_t* shapes_hw, int32_t N, int32_t S, int32_t M, int32_t Lq, int32_t L,
                                   int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream) {
+  return tce_msda_fused_valid_f32(value, proj, ref, out, shapes_hw, nullptr, N, S, M, Lq, L, P, ref_dim, ref_per_frame, stream);
+}
+
+extern "C" int tce_msda_fused_valid_f32(const float* value, const float* proj, const float* ref, float* out,
+                                        const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M,
+                                        int32_t Lq, int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame,
+                                        tceStream stream) {
   TCE_CHECK_ARG(value && proj && ref && out && shapes_hw, "tce_msda_fused_f32: null pointer");
   TCE_CHECK_ARG(N > 0 && S > 0 && M > 0 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 16,
                 "tce_msda_fused_f32: bad sizes (L*P must be <= 16)");
@@ -710,14 +727,21 @@ extern "C" int tce_msda_fused_f32(const float* value, const float* proj, const f
       lv.W[l] = shapes_hw[2 * l + 1];
       lv.start[l] = start;
       start += lv.H[l] * lv.W[l];
+      lv.hv[l] = valid_hw ? valid_hw[2 * l] : lv.H[l];
+      lv.wv[l] = valid_hw ? valid_hw[2 * l + 1] : lv.W[l];
+      TCE_CHECK_ARG(lv.hv[l] >= 1 && lv.hv[l] <= lv.H[l] && lv.wv[l] >= 1 && lv.wv[l] <= lv.W[l],
+                    "tce_msda_fused_f32: valid size of level %d outside 1..(H, W)", l);
+      lv.vry[l] = (float)lv.hv[l] / (float)lv.H[l];  // get_valid_ratio: valid rows / rows, in fp32 like the reference
+      lv.vrx[l] = (float)lv.wv[l] / (float)lv.W[l];
     } else {
-      lv.H[l] = lv.W[l] = 1;
+      lv.H[l] = lv.W[l] = lv.hv[l] = lv.wv[l] = 1;
       lv.start[l] = 0;
+      lv.vrx[l] = lv.vry[l] = 1.f;
     }
   }
   TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
   const long long total = (long long)N * Lq * M;
-  if (M == 8 && Lq >= 2048 && g_msda_lds && tce_aligned16(value) && tce_aligned16(out)) {
+  if (M == 8 && Lq >= 2048 && g_msda_lds && !valid_hw && tce_aligned16(value) && tce_aligned16(out)) {
     // LDS-staged form: the largest suffix of levels whose (frame, head) slice fits the LDS
     int first = L;
     while (first > 1 && (long long)(start - lv.start[first - 1]) * D * 4 <= MSDA_LDS_BYTES) --first;

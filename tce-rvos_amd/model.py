@@ -31,8 +31,9 @@ class NestedTensor(object):
 
     def to(self, device):
         nt = NestedTensor(self.tensors.to(device), self.mask.to(device) if self.mask is not None else None)
-        if hasattr(self, "unpadded"):
-            nt.unpadded = self.unpadded
+        for a in ("unpadded", "valid_hw"):
+            if hasattr(self, a):
+                setattr(nt, a, getattr(self, a))
         return nt
 
     def decompose(self):
@@ -58,8 +59,9 @@ def nested_tensor_from_videos_list(videos_list: List[torch.Tensor], size_divisib
         m[:v.shape[0], :v.shape[2], :v.shape[3]] = False
     nt = NestedTensor(vids, masks)
     # host shape metadata: no clip was padded iff every clip already has the batch's size (forward() then needs no
-    # device read-back of the mask to know it -- VERDICT r2 weak #10)
+    # device read-back of the mask to know it -- VERDICT r2 weak #10); valid_hw: each clip's un-padded frame size
     nt.unpadded = all(list(v.shape) == max_size for v in videos_list)
+    nt.valid_hw = [(int(v.shape[2]), int(v.shape[3])) for v in videos_list]
     return nt
 
 
@@ -434,8 +436,9 @@ class ReferFormer(nn.Module):
                 w[pre + ":f"] = wf.permute(0, 2, 3, 1).reshape(wf.shape[0], -1).contiguous()
 
     # ---------------------------------------------------------------- per-shape constants
-    def _shape_consts(self, T, H0, W0, device):
-        key = (T, H0, W0)
+    def _shape_consts(self, T, H0, W0, device, valid=None):
+        """valid = (rows, columns) of the frames that are not padding (None: un-padded)."""
+        key = (T, H0, W0, valid)
         c = self._shape_cache.get(key)
         if c is not None:
             return c
@@ -453,28 +456,58 @@ class ReferFormer(nn.Module):
             starts.append(starts[-1] + h * ww)
         F = cfg.hidden_dim // 2
         c = dict(sizes=sizes, lvl_sizes=lvl_sizes, S=S, starts=starts)
-        # backbone-level position maps (frame independent for un-padded clips): [h*w, 256]
-        c["pos"] = [ops.pos_sine2d(1, h, ww, F, device) for (h, ww) in sizes]
+
+        # Padded clips: the mask of every map is the nearest-neighbour resampling of the frame mask (backbone.py / Joiner,
+        # F.interpolate(mask[None].float(), size=...)); a bottom / right border stays one, so a map's mask is its count of
+        # non-padded rows / columns: src = min(floor(dst * in / out), in - 1) < valid  (scale in fp32 like PyTorch)
+        def nvalid(n_out, n_in, v_in):
+            if v_in >= n_in:
+                return n_out
+            src = torch.clamp(torch.floor(torch.arange(n_out, dtype=torch.float32) *
+                                          torch.tensor(float(n_in) / float(n_out), dtype=torch.float32)).long(), max=n_in - 1)
+            return int((src < v_in).sum())
+
+        Hv, Wv = valid if valid is not None else (H0, W0)
+        sizes_v = [(nvalid(h, H0, Hv), nvalid(ww, W0, Wv)) for (h, ww) in sizes]
+        lvl_v = [(nvalid(h, H0, Hv), nvalid(ww, W0, Wv)) for (h, ww) in lvl_sizes]
+        if valid is not None and any(a < 1 or b < 1 for a, b in sizes_v + lvl_v):
+            raise NotImplementedError("padded clip whose valid region vanishes at a pyramid level")
+        c["lvl_valid"] = lvl_v if valid is not None else None
+        # backbone-level position maps (the same for every frame: one clip's frames share their size): [h*w, 256]
+        c["pos"] = [ops.pos_sine2d(1, h, ww, F, device, valid=v) for (h, ww), v in zip(sizes, sizes_v)]
         # encoder position = sine + level embedding, concatenated over levels: [S, 256]
         lp = torch.empty(S, cfg.hidden_dim, dtype=torch.float32, device=device)
         for l, (h, ww) in enumerate(lvl_sizes):
-            ops.pos_sine2d(1, h, ww, F, device, add=w["transformer.level_embed"][l], out=lp[starts[l]:starts[l] + h * ww])
+            ops.pos_sine2d(1, h, ww, F, device, add=w["transformer.level_embed"][l], out=lp[starts[l]:starts[l] + h * ww],
+                           valid=lvl_v[l])
         c["lvl_pos"] = lp
-        # encoder reference points (pixel centres), get_reference_points :572-589 with valid_ratios == 1
+        # encoder reference points (pixel centres) / (valid_ratio * size), get_reference_points :572-589; the per-level factor
+        # "* valid_ratios" (:590-594) is applied inside the MSDA kernels
         refs = []
-        for (h, ww) in lvl_sizes:
+        for (h, ww), (hv, wv) in zip(lvl_sizes, lvl_v):
             ry, rx = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=torch.float32),
                                     torch.linspace(0.5, ww - 0.5, ww, dtype=torch.float32), indexing="ij")
-            refs.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / h), -1))
+            if valid is None:
+                refs.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / h), -1))
+            else:
+                vr_w, vr_h = torch.tensor(float(wv)) / ww, torch.tensor(float(hv)) / h
+                refs.append(torch.stack((rx.reshape(-1) / (vr_w * ww), ry.reshape(-1) / (vr_h * h)), -1))
         c["enc_ref"] = torch.cat(refs, 0).to(device).contiguous()
         # VLBlock reduced grids (segmentation.py:339-344): stage k=1..4 <-> sizes[k-1], sr = 8,4,2,1
-        red = {}
+        red, kmask = {}, {}
         for stage, sr in ((1, 8), (2, 4), (3, 2), (4, 1)):
             h, ww = sizes[stage - 1]
+            hv, wv = sizes_v[stage - 1]
             if sr > 1:
                 nh_, nw_ = int(h * 1.0 / sr), int(ww * 1.0 / sr)
                 red[stage] = (nh_, nw_, ops.resize_nearest(c["pos"][stage - 1], 1, h, ww, nh_, nw_, cfg.hidden_dim))
+                h, ww, hv, wv = nh_, nw_, nvalid(nh_, h, hv), nvalid(nw_, ww, wv)   # the map's mask, resampled again (:345-351)
+            if valid is not None:  # key padding mask of the block's self-attention over all frames' tokens: 1 = ignore
+                m = torch.ones(h, ww, dtype=torch.uint8)
+                m[:hv, :wv] = 0
+                kmask[stage] = m.reshape(-1).repeat(T).to(device).contiguous()
         c["red"] = red
+        c["kmask"] = kmask
         # built once per shape on the calling stream: forwards kept in flight on OTHER streams (slots) read them too
         torch.cuda.current_stream(device).synchronize()
         self._shape_cache[key] = c
@@ -537,10 +570,8 @@ class ReferFormer(nn.Module):
             raise NotImplementedError("valid_indices (A2D/JHMDB single-frame path) is outside the hot path")
         if not vids.is_cuda:
             raise RuntimeError("inputs must be on the GPU: this path has no CPU implementation")
-        if mask is not None and not getattr(samples, "unpadded", False) and bool(mask.any()):
-            # a NestedTensor built elsewhere carries no shape metadata: one device read-back decides
-            raise NotImplementedError("padded clips are not supported (a single clip is never padded)")
         frames = vids[0].to(torch.float32).contiguous()
+        valid = self._valid_region(samples, mask, frames)
         size = targets[0]["size"]
         img_h, img_w = float(size[0]), float(size[1])
         ids, att, ids_host = self._tokenise(captions, frames.device)
@@ -548,11 +579,11 @@ class ReferFormer(nn.Module):
         ops.range_poll(frames.device)  # split-fp16 range guard: a tripped flag of an EARLIER forward raises here
         cached = self._text_lookup(ids, ids_host)
         if cached is not None:  # text features of this expression are cached: the clip runs from them
-            out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot)
+            out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot, valid_hw=valid)
         else:
-            key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp)
+            key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp, valid)
             if not self._want_graph(key):
-                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot)
+                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, valid=valid)
             else:
                 # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder
                 # beside the pixel decoder
@@ -563,13 +594,34 @@ class ReferFormer(nn.Module):
                     def text_fn(alloc):
                         return self._text_plan().forward(st[1], alloc)
 
-                    ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res), frames, slot)
+                    ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, valid=valid), frames, slot)
                 if ent is None:  # the capture's arenas did not fit this shape's fallback kernels: eager from now on
-                    out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot)
+                    out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot,
+                                    valid=valid)
                 else:
                     out = self._replay(key, ent, (frames, ids))
         ops.range_snapshot_async(frames.device)
         return out
+
+    @staticmethod
+    def _valid_region(samples, mask, frames):
+        """(rows, columns) of the clip's frames that are NOT padding, or None for an un-padded clip.  Padding = a rectangular
+        border at the bottom / right, the same in every frame (what nested_tensor_from_videos_list produces, util/misc.py:
+        354-377); any other mask is rejected.  Host metadata when the NestedTensor carries it, else ONE device read-back."""
+        if mask is None or getattr(samples, "unpadded", False):
+            return None
+        H, W = int(frames.shape[-2]), int(frames.shape[-1])
+        vhw = getattr(samples, "valid_hw", None)
+        if vhw is not None:
+            hv, wv = vhw[0]
+        else:
+            m = mask[0]
+            hv, wv = int((~m[0, :, 0]).sum()), int((~m[0, 0, :]).sum())
+            rect = torch.ones(H, W, dtype=torch.bool, device=m.device)
+            rect[:hv, :wv] = False
+            if hv < 1 or wv < 1 or not bool((m == rect[None]).all()):
+                raise NotImplementedError("padding masks other than a bottom / right border shared by all frames are not supported")
+        return None if (hv, wv) == (H, W) else (int(hv), int(wv))
 
     def _want_graph(self, key):
         """Graph replay for shapes that come back; eager launches for the first `graph_after` sightings of a shape."""
@@ -646,13 +698,13 @@ class ReferFormer(nn.Module):
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
-    def _run(self, frames, text, img_h, img_w, res, slot=0):
+    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None):
         from .pipeline import run_clip
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
-            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot))
+            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot), valid=valid)
         arena, side_arena, side_stream, arena2, stream2, arena3, stream3, arena4, stream4 = res
-        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False,
+        return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False, valid=valid,
                         fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
                         fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
@@ -735,20 +787,26 @@ class ReferFormer(nn.Module):
         return hid[None], pooled[None]
 
     @torch.no_grad()
-    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w, slot=0):
-        """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768]."""
+    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w, slot=0, valid_hw=None):
+        """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768].  valid_hw = (rows,
+        columns) of the frames that are not padding (a clip zero-padded at the bottom / right; None: un-padded)."""
+        if valid_hw is not None:
+            valid_hw = (int(valid_hw[0]), int(valid_hw[1]))
+            if valid_hw == (int(frames.shape[-2]), int(frames.shape[-1])):
+                valid_hw = None
         self._ensure_packed()
         text_hidden, text_pooled = text_hidden.contiguous(), text_pooled.contiguous()
         key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training, int(slot),
-               self._stamp)
+               self._stamp, valid_hw)
         if not self._want_graph(key):
-            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot)
+            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw)
         ent = self._graphs.get(key)
         if ent is None:
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
-            ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res), frames, slot)
+            ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res, valid=valid_hw), frames,
+                                slot)
             if ent is None:
-                return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot)
+                return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw)
         return self._replay(key, ent, (frames, text_hidden, text_pooled))
 
 

@@ -485,15 +485,17 @@ class MSDeformAttnFunction(torch.autograd.Function):
         return gv, None, None, gl, ga, None, None
 
 
-def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_frame, out=None, alloc=None):
+def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_frame, out=None, alloc=None, valid_hw=None):
+    """valid_hw: per level (rows, columns) that are not padding (padded clips; None = un-padded)."""
     _chk(value, "value")
     if out is None:
         out = alloc(N * Lq, M * 32) if alloc else torch.empty(N * Lq, M * 32, dtype=torch.float32, device=value.device)
     arr = (C.c_int32 * (2 * L))(*[int(v) for hw in shapes_hw for v in hw])
+    varr = (C.c_int32 * (2 * L))(*[int(v) for hw in valid_hw for v in hw]) if valid_hw is not None else None
 
     def go():
-        check(lib().tce_msda_fused_f32(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), arr, N, S, M, Lq,
-                                       L, P, ref_dim, 1 if ref_per_frame else 0, _stream()), "tce_msda_fused_f32")
+        check(lib().tce_msda_fused_valid_f32(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), arr, varr, N, S,
+                                             M, Lq, L, P, ref_dim, 1 if ref_per_frame else 0, _stream()), "tce_msda_fused_f32")
     if HBM_PROFILE is None:
         go()
         return out
@@ -506,11 +508,13 @@ def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_
     return out
 
 
-def pos_sine2d(T, h, w, F, device, add=None, out=None, alloc=None):
+def pos_sine2d(T, h, w, F, device, add=None, out=None, alloc=None, valid=None):
+    """valid = (hv, wv): rows / columns of the map that are not padding (padded clips)."""
     if out is None:
         out = alloc(T * h * w, 2 * F) if alloc else torch.empty(T * h * w, 2 * F, dtype=torch.float32, device=device)
-    check(lib().tce_pos_sine2d_f32(out.data_ptr(), add.data_ptr() if add is not None else None, T, h, w, F, _stream()),
-          "tce_pos_sine2d_f32")
+    hv, wv = (h, w) if valid is None else valid
+    check(lib().tce_pos_sine2d_valid_f32(out.data_ptr(), add.data_ptr() if add is not None else None, T, h, w, F, hv, wv,
+                                         _stream()), "tce_pos_sine2d_f32")
     return out
 
 

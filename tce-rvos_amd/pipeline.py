@@ -81,14 +81,15 @@ class _Fork:
 
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-             fork3=None):
-    """The clip's launch program with the model's own packed-weight routes active (ops.Routes)."""
+             fork3=None, valid=None):
+    """The clip's launch program with the model's own packed-weight routes active (ops.Routes).  valid = (rows, columns) of
+    the frames that are not padding (None: un-padded clip)."""
     with ops.routes(model._routes):
-        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3)
+        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid)
 
 
 def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-              fork3=None):
+              fork3=None, valid=None):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
@@ -104,7 +105,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     if side_arena is not None:
         side_arena.reset()
     A = ar.alloc
-    sc = model._shape_consts(T, H0, W0, dev)
+    sc = model._shape_consts(T, H0, W0, dev, valid)
+    lvl_valid = sc["lvl_valid"]  # per-level (rows, columns) that are not padding, or None
     sizes, lvl_sizes, S, starts = sc["sizes"], sc["lvl_sizes"], sc["S"], sc["starts"]
     Q = cfg.num_queries
     ff = cfg.dim_feedforward
@@ -348,7 +350,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
             fk_s.join()
             samp = ops.msda_fused(value, proj, ref_t, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
-                                  out=A(q_rows, D))
+                                  out=A(q_rows, D), valid_hw=lvl_valid)
             FR(samp, q_rows, D, [(w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, D, D, False, ops.FR_NONE)],
                res=resid, ldres=D)
             ln_(resid, norm)
@@ -380,7 +382,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         else:
             offaw()
         samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
-                              out=A(q_rows, D))
+                              out=A(q_rows, D), valid_hw=lvl_valid)
         if norm:
             _proj_res_ln(samp, w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, q_rows,
                          w[norm + ".weight"], w[norm + ".bias"])
@@ -797,7 +799,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                     lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
             v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(n_low, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A,
+                         kmask=sc["kmask"].get(stage))  # padded clips: padded positions are no keys (segmentation.py:345-356)
             o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
             ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
         else:
@@ -807,7 +810,7 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                     batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
             v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(n, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A)
+            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A, kmask=sc["kmask"].get(stage))
             gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                     ldres=D, res_mode=RES_ADD)
         arx.release(m1)

@@ -1078,3 +1078,56 @@ def test_gemm_splitk_with_layernorm(ops, M, N, K, splits, res):
                 res_mode=ops.RES_ADD if res else ops.RES_NONE, splitk=splits, ws=ws if splits > 1 else None,
                 ln=(dev(gam), dev(bet)), ln_eps=1e-12)
     close(dx, ref, 2e-4, 2e-4)
+
+
+@pytest.mark.parametrize("N,Lq,ref_dim", [(2, 300, 2), (3, 5, 4), (2, 700, 2)])
+def test_msda_fused_padded_levels(ops, N, Lq, ref_dim):
+    """tce_msda_fused_valid_f32: reference points scaled per level by the valid ratios (tce_deformable_transformer.py:125-132,
+    590-594, 654-656) and the value rows of padded positions read as zero (ms_deform_attn.py:96-97) -- both kernel forms."""
+    g = torch.Generator().manual_seed(Lq + ref_dim)
+    M, L, P = 8, 4, 4
+    shapes = [(9, 13), (5, 7), (3, 4), (2, 2)]
+    valid = [(7, 10), (4, 5), (2, 3), (1, 2)]
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(N, S, M, 32, generator=g)
+    proj = torch.randn(N, Lq, M * L * P * 3, generator=g)
+    proj[..., :M * L * P * 2] *= 2.0
+    ref = torch.rand(N, Lq, ref_dim, generator=g) * 1.2 - 0.1
+    off = proj[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+    aw = torch.softmax(proj[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    vr = torch.tensor([[wv / w, hv / h] for (h, w), (hv, wv) in zip(shapes, valid)], dtype=torch.float32)   # (w, h) per level
+    if ref_dim == 2:
+        refl = ref[:, :, None, :] * vr[None, None]
+        norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+        loc = refl[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        refl = ref[:, :, None, :] * torch.cat([vr, vr], -1)[None, None]
+        loc = refl[:, :, None, :, None, :2] + off / P * refl[:, :, None, :, None, 2:] * 0.5
+    pad = torch.cat([torch.ones(h, w, dtype=torch.bool).index_put_(
+        (torch.arange(hv)[:, None], torch.arange(wv)[None, :]), torch.tensor(False)).reshape(-1)
+        for (h, w), (hv, wv) in zip(shapes, valid)])
+    expect = O.msda_core(value.masked_fill(pad[None, :, None, None], 0.0), shapes, loc, aw)
+    out = ops.msda_fused(dev(value), dev(proj), dev(ref), shapes, N, S, M, Lq, L, P, ref_dim, True, valid_hw=valid)
+    close(out.view(N, Lq, M * 32), expect, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("h,w,hv,wv", [(9, 13, 7, 10), (12, 20, 12, 17), (6, 10, 5, 10)])
+def test_pos_sine2d_padded(ops, h, w, hv, wv):
+    """Position map of a padded grid (position_encoding.py:64-84 with a mask): exact on the valid region.  At padded positions
+    the reference's embedding is (0 - 0.5) / 1e-6 * 2 pi = -3.1e6, whose sin / cos depend on the last bit of pow(10000, .)
+    -- no two implementations agree there -- so there the test checks the ARGUMENT the kernel uses (via the channel whose
+    divisor is 1) and that the values are sines / cosines of something (bounded, sin^2 + cos^2 = 1 per channel pair)."""
+    mask = torch.ones(2, h, w, dtype=torch.bool)
+    mask[:, :hv, :wv] = False
+    ref = O.pos_sine_2d(mask, 128).permute(0, 2, 3, 1)       # [2, h, w, 256]
+    out = ops.pos_sine2d(2, h, w, 128, "cuda", valid=(hv, wv)).view(2, h, w, 256).cpu()
+    close(out[:, :hv, :wv], ref[:, :hv, :wv], 1e-5, 1e-5)
+    assert torch.isfinite(out).all() and out.abs().max() <= 1.0 + 1e-6
+    pairs = out.view(2, h, w, 128, 2)
+    close(pairs.pow(2).sum(-1), torch.ones(2, h, w, 128), 1e-5, 1e-5)
+    # channels 0 / 1 (divisor 10000^0 = 1): sin / cos of the embedding itself -- equal to the reference's wherever the embedding is
+    # small (valid rows of padded columns: y-embedding 0 there means (0 - 0.5) / 1e-6, but the x-embedding of a padded ROW ...)
+    if wv < w:   # padded columns, valid rows: the x channels (128..) carry min(x + 1, wv) = wv, an ordinary angle
+        close(out[:, :hv, wv:, 128:], ref[:, :hv, wv:, 128:], 1e-5, 1e-5)
+    if hv < h:   # padded rows, valid columns: the y channels carry hv
+        close(out[:, hv:, :wv, :128], ref[:, hv:, :wv, :128], 1e-5, 1e-5)
