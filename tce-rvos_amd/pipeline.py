@@ -484,7 +484,10 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             ffn(src, T * S, fp, norm=fp + "norm4")
             tap(f"L{i}.src4", src)
         if "enc_msda" not in ABLATE:
-            msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1")
+            # the offsets|weights projection (src + pos) and the value projection (src) are independent 24100-row GEMMs of 1.1 and
+            # 0.74 workgroup rounds: side by side they pack into 1.9 rounds instead of 3 (TCE_ENCFORK=0: one after the other)
+            msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1",
+                 small_fork=_Fork(tok_stream) if os.environ.get("TCE_ENCFORK", "1") != "0" else None)
         ffn(src, T * S, lp, norm=lp + "norm2")
         tap(f"L{i}.src6", src)
         if ar2 is not None and stream2 is not None and lat1_when == f"enc{i}":
