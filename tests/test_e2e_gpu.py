@@ -642,14 +642,15 @@ def test_unit_scale_mask_logits_in_mixed_fp16(models):
         model.repack()
 
 
-def test_padded_clip_matches_oracle(models):
+@pytest.mark.parametrize("backbone", ["swin_t_p4w7", "resnet50", "video_swin_t_p4w7"])
+def test_padded_clip_matches_oracle(models, backbone):
     """VERDICT r2 'missing' #3: a clip zero-padded at the bottom / right (what nested_tensor_from_videos_list produces with
     size_divisibility, util/misc.py:354-377): mask pyramid, masked position maps, valid ratios on every reference point, zero
     value rows at padded positions, key padding masks in the VisionLanguageBlocks' self-attention -- against the oracle run
     with the same pad mask.  Host shape metadata: no device read-back; a foreign NestedTensor costs one and gives the same
     bits; masks that are not a bottom / right border are rejected."""
     from tce_rvos_amd import nested_tensor_from_videos_list, NestedTensor
-    model = models("swin_t_p4w7", 31)
+    model = models(backbone, 31)
     T, hv, wv = 3, 90, 140
     clip = synth_frames(T, hv, wv, 61)
     nt = nested_tensor_from_videos_list([clip.cuda()], size_divisibility=32)
@@ -665,7 +666,9 @@ def test_padded_clip_matches_oracle(models):
         assert torch.equal(outs[0][k], outs[2][k]), k
     hid, pooled = model.forward_text_encoder(ids, "cuda")
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
-    ref = O.forward(sd, O.OracleConfig(), nt.tensors[0].cpu(), hid.cpu(), pooled.cpu(), img_size=(H, W), pad_mask=nt.mask[0].cpu())
+    bb = __import__("tce_rvos_amd.config", fromlist=["BACKBONES"]).BACKBONES[backbone]
+    ocfg = O.OracleConfig(backbone=backbone, **{k: bb[k] for k in ("embed_dim", "depths", "num_heads") if k in bb})
+    ref = O.forward(sd, ocfg, nt.tensors[0].cpu(), hid.cpu(), pooled.cpu(), img_size=(H, W), pad_mask=nt.mask[0].cpu())
     out = outs[0]
     for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("reference_points", 1e-4)):
         d = (out[k].cpu() - ref[k]).abs().max().item()
