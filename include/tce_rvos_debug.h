@@ -25,6 +25,11 @@ int tce_debug_mha_set_split(int32_t on);
 /* tuning aid: 1 (default) = tce_msda_fused_f32 runs calls of <= 8192 (frame, query, head) items with one wavefront per item
  * (all 16 sampling points in flight); 0 = always 8 lanes per item (A/B timing and parity) */
 int tce_debug_msda_set_fewq(int32_t on);
+/* experiment (tools/pair_graph_probe.py): graphs = n hipGraph_t handles of captured clips (each with its own buffers); builds
+ * ONE executable in which they are n components with no edge between them (every node re-created with its parameters and
+ * edges; TCE_GROUP_CHILD=1: as child-graph nodes instead), launched with tce_graph_launch.  Bit-identical to single replays
+ * and not faster (x1.01 at config 2; child-graph nodes x0.75): see DESIGN.md section 3.8.  The inputs are cloned. */
+int tce_graph_group(void* const* graphs, int32_t n, void** graph_exec_out);
 #ifdef __cplusplus
 }
 #endif

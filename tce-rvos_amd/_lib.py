@@ -130,6 +130,7 @@ DEBUG_SIGNATURES = {
     "tce_debug_window_attn_set_mfma": (i32, [i32]),
     "tce_debug_mha_set_split": (i32, [i32]),
     "tce_debug_msda_set_fewq": (i32, [i32]),
+    "tce_graph_group": (i32, [C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p)]),
 }
 
 _LIB = None

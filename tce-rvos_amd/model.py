@@ -740,9 +740,12 @@ class ReferFormer(nn.Module):
             warnings.warn(f"tce_rvos_amd: graph capture of {key[:2]} skipped ({e}); this shape runs eagerly", RuntimeWarning)
             return None
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        keep = os.environ.get("TCE_KEEP_GRAPHS", "0") == "1"  # keep the hipGraph_t beside the executable (clip groups)
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = fn(res)
+        if keep:
+            graph.instantiate()
         _ALL_GRAPHS.append(graph)  # executables outlive their cache entry (see _ALL_GRAPHS)
         try:
             plan = ops.CopyPlan(_flat_outputs(out)) if os.environ.get("TCE_COPYPLAN", "1") != "0" else None

@@ -2,7 +2,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3v
 mkdir -p $O
-python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
-tail -3 $O/tests.log
-python tools/replay_latency.py 2>&1 | tail -1
-python tools/msda_bench.py > $O/msda.txt 2>&1 || true; tail -8 $O/msda.txt
+rm -f $O/queues_sweep.txt
+for q in 5 6 3; do
+  echo "GPU_MAX_HW_QUEUES=$q" >> $O/queues_sweep.txt
+  GPU_MAX_HW_QUEUES=$q timeout -k 10 300 python tools/pair_graph_probe.py --n 2 >> $O/queues_sweep.txt 2>&1 || { tail -40 $O/queues_sweep.txt; exit 1; }
+done
+grep -v amdgpu.ids $O/queues_sweep.txt
