@@ -186,42 +186,70 @@ __global__ void __launch_bounds__(256) mask_pack_kernel(const float* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) mask_tail_kernel(const float* __restrict__ G, const float* __restrict__ tail,
+// Pixel-stationary: a thread owns one pixel of frame t and walks a chunk of the frame's (level, query) items, whose packed
+// tails sit in LDS (16-byte broadcast reads).  The pixel's G row ([nl*Q*DC] floats, contiguous) is read once by its own
+// thread, so every 128-byte line of G comes from HBM once -- the first form (one launch row per item, each reading 32 of a
+// line's 128 bytes) fetched G four times over (190 MB against 52 MB algorithmic, profiles/r02_pmc_traffic.json).  (Reading
+// the wave-uniform tails through the scalar cache instead of LDS was tried: 45 us against 24 -- one s_load round trip per item.)
+constexpr int TAIL_ITEMS = 8;  // items per workgroup = a thread's serial chain (config 2: 20.8 us with all 20 items in one
+                               // thread, 16.0 us at 8; the first form 28.3 us); the chunks of one pixel block are neighbours
+                               // in blockIdx.x, so they meet G's lines in cache
+__global__ void __launch_bounds__(128) mask_tail_kernel(const float* __restrict__ G, const float* __restrict__ tail,
                                                         const float* __restrict__ refs, int ref_ld,
                                                         float* __restrict__ masks, int nl, int T, int Q, int h, int w,
                                                         float img_h, float img_w, int stride_px) {
-  __shared__ float sp[TAIL_LD];
-  __shared__ float sref[2];
-  const int item = blockIdx.y;  // (lvl*T + t)*Q + q
-  const int q = item % Q, t = (item / Q) % T, lvl = item / (Q * T);
-  const float* tl = tail + ((long long)lvl * T * Q + t * Q + q) * TAIL_LD;
-  if (threadIdx.x < TAIL_LD) sp[threadIdx.x] = tl[threadIdx.x];
-  if (threadIdx.x < 2) sref[threadIdx.x] = refs[((long long)lvl * T * Q + t * Q + q) * ref_ld + threadIdx.x];
+  __shared__ __attribute__((aligned(16))) float sp[TAIL_ITEMS * TAIL_LD];
+  __shared__ float sref[TAIL_ITEMS * 2];
+  const int t = blockIdx.y;
+  const int nitem = nl * Q;
+  const int nchunk = (nitem + TAIL_ITEMS - 1) / TAIL_ITEMS;
+  const int chunk = blockIdx.x % nchunk, pblock = blockIdx.x / nchunk;
+  const int it0 = chunk * TAIL_ITEMS, itn = min(TAIL_ITEMS, nitem - it0);
+  for (int i = threadIdx.x; i < itn * (TAIL_LD / 4); i += 128) {
+    const int it = it0 + i / (TAIL_LD / 4), lvl = it / Q, q = it - lvl * Q;
+    reinterpret_cast<f32x4*>(sp)[i] =
+        reinterpret_cast<const f32x4*>(tail + ((long long)lvl * T * Q + t * Q + q) * TAIL_LD)[i % (TAIL_LD / 4)];
+  }
+  for (int i = threadIdx.x; i < itn * 2; i += 128) {
+    const int it = it0 + (i >> 1), lvl = it / Q, q = it - lvl * Q;
+    sref[i] = refs[((long long)lvl * T * Q + t * Q + q) * ref_ld + (i & 1)];
+  }
   __syncthreads();
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix = pblock * 128 + threadIdx.x;
   const int hw = h * w;
   if (pix >= hw) return;
   const int y = pix / w, x = pix - y * w;
-  const int ncol = nl * Q * DC;
-  const float* g = G + ((long long)t * hw + pix) * ncol + (lvl * Q + q) * DC;
-  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
-  const float relx = sref[0] * img_w - (float)(x * stride_px + stride_px / 2);
-  const float rely = sref[1] * img_h - (float)(y * stride_px + stride_px / 2);
-  float h0[DC];
+  const float px = (float)(x * stride_px + stride_px / 2), py = (float)(y * stride_px + stride_px / 2);
+  const float* g = G + ((long long)t * hw + pix) * (nitem * DC) + (long long)it0 * DC;
+#pragma unroll 2
+  for (int i = 0; i < itn; ++i) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(sp + i * TAIL_LD);
+    float s[TAIL_LD - 4];  // 108 floats: the 105 used + padding
 #pragma unroll
-  for (int c = 0; c < DC; ++c) {
-    const float gv = c < 4 ? g0[c] : g1[c - 4];
-    h0[c] = fmaxf(gv + sp[c] * relx + sp[8 + c] * rely + sp[16 + c], 0.f);
+    for (int j = 0; j < (TAIL_LD - 4) / 4; ++j) {
+      const f32x4 v = s4[j];
+      s[4 * j] = v[0]; s[4 * j + 1] = v[1]; s[4 * j + 2] = v[2]; s[4 * j + 3] = v[3];
+    }
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + i * DC), g1 = *reinterpret_cast<const f32x4*>(g + i * DC + 4);
+    const float relx = sref[2 * i] * img_w - px;
+    const float rely = sref[2 * i + 1] * img_h - py;
+    float h0[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      const float gv = c < 4 ? g0[c] : g1[c - 4];
+      h0[c] = fmaxf(gv + s[c] * relx + s[8 + c] * rely + s[16 + c], 0.f);
+    }
+    float o = s[104];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      float a = s[88 + c];
+#pragma unroll
+      for (int k = 0; k < DC; ++k) a = fmaf(s[24 + c * DC + k], h0[k], a);
+      o = fmaf(s[96 + c], fmaxf(a, 0.f), o);
+    }
+    const int it = it0 + i, lvl = it / Q, q = it - lvl * Q;
+    masks[(((long long)lvl * T + t) * Q + q) * hw + pix] = o;
   }
-  float o = sp[104];
-#pragma unroll
-  for (int c = 0; c < DC; ++c) {
-    float a = sp[88 + c];
-#pragma unroll
-    for (int k = 0; k < DC; ++k) a = fmaf(sp[24 + c * DC + k], h0[k], a);
-    o = fmaf(sp[96 + c], fmaxf(a, 0.f), o);
-  }
-  masks[((long long)item) * hw + pix] = o;
 }
 
 // One launch for a list of copies (the graph's input staging and the clones of its output tensors): blockIdx.y picks the
@@ -354,8 +382,8 @@ extern "C" int tce_mask_tail_f32(const float* G, const float* tail, const float*
   TCE_CHECK_ARG(G && tail && refs && masks && nl > 0 && T > 0 && Q > 0 && h > 0 && w > 0 && ref_ld >= 2,
                 "tce_mask_tail_f32: bad arguments");
   TCE_CHECK_ARG(tce_aligned16(G), "tce_mask_tail_f32: G must be 16-byte aligned");
-  hipLaunchKernelGGL(mask_tail_kernel, dim3(tce_cdiv(h * w, 256), nl * T * Q), dim3(256), 0, (hipStream_t)stream, G,
-                     tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px);
+  hipLaunchKernelGGL(mask_tail_kernel, dim3(tce_cdiv(h * w, 128) * tce_cdiv(nl * Q, TAIL_ITEMS), T), dim3(128), 0,
+                     (hipStream_t)stream, G, tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px);
   TCE_CHECK_LAUNCH("tce_mask_tail_f32");
   return TCE_OK;
 }

@@ -399,9 +399,11 @@ def test_small_elementwise(ops):
         close(ops.box_refine(dev(tmp), dev(ref)), torch.sigmoid(t2), 1e-5, 1e-6)
 
 
-def test_dynamic_mask_head(ops):
+@pytest.mark.parametrize("nl,T,Q,h,w", [(3, 2, 5, 18, 25), (3, 2, 30, 9, 15), (1, 1, 1, 5, 131)])
+def test_dynamic_mask_head(ops, nl, T, Q, h, w):
+    """(3, 2, 30): 90 (level, query) items = two item chunks of the pixel-stationary kernel; (1, 1, 1): a single item."""
     g = torch.Generator().manual_seed(9)
-    nl, T, Q, Cm, h, w = 3, 2, 5, 64, 18, 25
+    Cm = 64
     cfg = O.OracleConfig(mask_dim=Cm)
     npar = 8 * (Cm + 2) + 64 + 8 + 8 + 8 + 1
     feats = torch.randn(T, Cm, h, w, generator=g)

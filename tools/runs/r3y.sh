@@ -1,6 +1,14 @@
+set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python tools/replay_latency.py 2>&1 | tail -1
-TCE_ENCFORK=0 python tools/replay_latency.py 2>&1 | tail -1
-python tools/replay_latency.py 2>&1 | tail -1
-TCE_ENCFORK=0 python tools/replay_latency.py 2>&1 | tail -1
-python tools/graph_vs_eager.py 2>&1 | grep -v amdgpu | head -1
+O=gpurun_out/r3y
+mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+tail -3 $O/tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
+tail -2 $O/smoke.log
+python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+python - <<'PY'
+import json
+b=json.loads(open('gpurun_out/r3y/bench.json').read().strip().splitlines()[-1])
+print({k:b[k] for k in ('value','ms_per_step','value_c2','value_text_cached')}, b['roofline']['frac'], b['parity'])
+PY
