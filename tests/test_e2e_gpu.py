@@ -234,6 +234,31 @@ def test_flag_combinations_match_oracle(flags):
             assert (a["pred_masks"].cpu() - b["pred_masks"]).abs().max().item() < 5e-3
 
 
+@pytest.mark.parametrize("L", [33, 70])
+def test_captions_longer_than_32_tokens_match_oracle(models, L):
+    """More than 32 text tokens: the five text cross-attention sites leave the folded one-launch form (built for <= 32 keys,
+    csrc/chain.hip) for q-projection + attention over L keys + output projection (segmentation.py:366-371, tce_rvos.py:283-291);
+    eager launches and graph replays of that form against the oracle."""
+    model = models("swin_t_p4w7", 31)
+    T, H, W = 3, 80, 120
+    frames = synth_frames(T, H, W, 6)
+    g = torch.Generator().manual_seed(L)
+    hid, pooled = torch.randn(L, 768, generator=g), torch.tanh(torch.randn(768, generator=g))
+    outs = []
+    for _ in range(4):  # eager sightings first, then the captured graph
+        outs.append(model.forward_features(frames.cuda(), hid.cuda(), pooled.cuda(), float(H), float(W)))
+    torch.cuda.synchronize()
+    out = outs[0]
+    sd = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    with torch.no_grad():
+        ref = O.forward(sd, O.OracleConfig(), frames, hid[None], pooled[None], img_size=(H, W))
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("pred_masks", 5e-3)):
+        d = (out[k].cpu() - ref[k]).abs().max().item()
+        assert d < tol, (L, k, d)
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "memory"):
+        assert torch.equal(outs[-1][k], out[k]), k
+
+
 @pytest.mark.parametrize("layers,L", [(1, 7), (12, 32), (2, 100)])
 def test_text_encoder_hip_matches_huggingface(layers, L):
     """RoBERTa on the HIP kernels vs HuggingFace's own forward of the same module (same weights, same ids)."""
