@@ -577,10 +577,11 @@ class ReferFormer(nn.Module):
         ids, att, ids_host = self._tokenise(captions, frames.device)
         self._ensure_packed()
         ops.range_poll(frames.device)  # split-fp16 range guard: a tripped flag of an EARLIER forward raises here
-        cached = self._text_lookup(ids, ids_host)
+        cached = self._text_lookup(ids, ids_host, frames.device)
         if cached is not None:  # text features of this expression are cached: the clip runs from them
             out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot, valid_hw=valid)
         else:
+            ids = ids.to(frames.device)
             key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp, valid)
             if not self._want_graph(key):
                 out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, valid=valid)
@@ -652,7 +653,7 @@ class ReferFormer(nn.Module):
         return graph_state()
 
     # ---------------------------------------------------------------- per-expression text cache
-    def _text_lookup(self, ids, ids_host=None):
+    def _text_lookup(self, ids, ids_host=None, device=None):
         """(last_hidden_state [L,768], pooler_output [768]) of a cached expression or None.  The reference recomputes
         RoBERTa for every clip of an expression (tce_rvos.py:406-424 inside forward; inference_ytvos.py:184-230 loops
         the clips); with `text_cache_size > 0` the features are computed once per distinct token sequence.  The
@@ -662,6 +663,7 @@ class ReferFormer(nn.Module):
         key = tuple(int(v) for v in (ids if ids_host is None else ids_host).reshape(-1).tolist())  # device ids: one sync
         ent = self._text_cache.get(key)
         if ent is None:
+            ids = ids.to(device) if device is not None else ids
             hid, pooled = self._text_plan().forward(
                 ids, lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ids.device))
             ent = (hid, pooled)
@@ -683,7 +685,9 @@ class ReferFormer(nn.Module):
                 raise NotImplementedError("padded captions (B > 1) are not supported")
         else:  # token ids: every position is a token (no device read-back here: it would serialise consecutive clips)
             ids, att = captions, None
-        return ids.to(device), (att.to(device) if att is not None else None), (None if ids.is_cuda else ids)
+        # host ids stay on the host until something needs them on the device (a cache hit never does: an H2D copy of pageable
+        # memory per clip would wait for the stream and stop the host from running ahead of the GPU)
+        return ids, att, (None if ids.is_cuda else ids)
 
     def _text_plan(self):
         """RoBERTa on the HIP kernels (text_encoder.py); the HF module only owns the weights."""
@@ -785,6 +789,7 @@ class ReferFormer(nn.Module):
     def forward_text_encoder(self, captions, device):
         """tce_rvos.py:406-424 up to the RoBERTa outputs: (last_hidden_state [1,L,768], pooler_output [1,768])."""
         ids, att, _ = self._tokenise(captions, device)
+        ids = ids.to(device)
         hid, pooled = self._text_plan().forward(
             ids, lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ids.device))
         return hid[None], pooled[None]
