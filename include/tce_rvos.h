@@ -227,7 +227,7 @@ int tce_box_refine_f32(const float* tmp, const float* ref, float* out, int32_t n
  *                         tail [nl, T*Q, 112] (w0x[8], w0y[8], b0[8], w1[64], b1[8], w2[8], b2, pad)
  *   (first layer = tce_gemm_f32 batched over frames: G[T, hw, nl*Q*8] = feats[T, hw, Cm] @ w0f[t]^T)
  *   tce_mask_tail_f32: G + relative coords (ref*(img_w,img_h) - (x*4+2, y*4+2)) -> ReLU -> 8x8 -> ReLU -> 8->1
- *                      -> masks [nl, T, Q, h, w]. */
+ *                      -> masks [nl, T, Q, h, w].  G and tail 16-byte aligned. */
 int tce_mask_pack_f32(const float* params, float* w0f, float* tail, int32_t nl, int32_t T, int32_t Q, int32_t Cm,
                       tceStream stream);
 int tce_mask_tail_f32(const float* G, const float* tail, const float* refs /* [nl, T*Q, ref_ld] */, int32_t ref_ld,

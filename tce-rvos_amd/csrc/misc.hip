@@ -381,7 +381,8 @@ extern "C" int tce_mask_tail_f32(const float* G, const float* tail, const float*
                                  int32_t stride_px, tceStream stream) {
   TCE_CHECK_ARG(G && tail && refs && masks && nl > 0 && T > 0 && Q > 0 && h > 0 && w > 0 && ref_ld >= 2,
                 "tce_mask_tail_f32: bad arguments");
-  TCE_CHECK_ARG(tce_aligned16(G), "tce_mask_tail_f32: G must be 16-byte aligned");
+  TCE_CHECK_ARG(tce_aligned16(G) && tce_aligned16(tail), "tce_mask_tail_f32: G and tail must be 16-byte aligned");
+  TCE_CHECK_ARG((nl * Q * DC) % 4 == 0, "tce_mask_tail_f32: G rows must be whole 16-byte units");
   hipLaunchKernelGGL(mask_tail_kernel, dim3(tce_cdiv(h * w, 128) * tce_cdiv(nl * Q, TAIL_ITEMS), T), dim3(128), 0,
                      (hipStream_t)stream, G, tail, refs, ref_ld, masks, nl, T, Q, h, w, img_h, img_w, stride_px);
   TCE_CHECK_LAUNCH("tce_mask_tail_f32");
