@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtce_rvos.so")
+LIB_PATH = os.environ.get("TCE_LIB") or os.path.join(HERE, "lib", "libtce_rvos.so")  # TCE_LIB: A/B of two builds (tools)
 
 c_f = C.c_void_p  # device pointers travel as integers
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float

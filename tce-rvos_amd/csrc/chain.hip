@@ -613,8 +613,11 @@ struct LinArgs {
   int single;
 };
 
+// K = 96 (Swin-T stage 0) is compiled for THREE workgroups per CU (168 registers, 43 KB of LDS): at config 2 the stage has
+// 72000 rows = 563 row blocks, one more than two per CU hold (512) -- a second, nearly empty round.  47.7 -> 38.5 us for the
+// norm1 -> qkv launch (profiles/r03_rowlin_occupancy.txt).
 template <int K, bool ROW>
-__global__ void __launch_bounds__(256, ROW ? 1 : 2) rowlin_kernel(const LinArgs p) {
+__global__ void __launch_bounds__(256, ROW ? 1 : (K <= 96 ? 3 : 2)) rowlin_kernel(const LinArgs p) {
   // The ring holds HALF blocks (the first / second K/32 k-steps of a 32-channel tile, hi and lo pieces interleaved,
   // padded to a multiple of 4 pieces so that every wave issues the same number of DMAs): three half-stages, the DMA of
   // half h+2 is issued while half h is multiplied.  3 x 16 KiB + staging tiles = 66 KiB at K = 256: two workgroups
