@@ -2,15 +2,12 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3u
 mkdir -p $O
-SH="--shapes 72000x288x96,72000x96x96,72000x256x96"
-echo "old build" > $O/rowlin_ab.txt
-TCE_LIB=$GRAFT_REPO_ROOT/tce-rvos_amd/lib/ab/libtce_old.so python tools/rowlin_bench.py $SH 2>&1 | grep -v amdgpu >> $O/rowlin_ab.txt
-echo "new build (3 workgroups per CU at K = 96)" >> $O/rowlin_ab.txt
-python tools/rowlin_bench.py $SH 2>&1 | grep -v amdgpu >> $O/rowlin_ab.txt
-cat $O/rowlin_ab.txt
-python -m pytest tests/test_kernels_gpu.py -x -q -k "rowlin" > $O/t6.log 2>&1 || { tail -40 $O/t6.log; exit 1; }
-tail -2 $O/t6.log
-TCE_LIB=$GRAFT_REPO_ROOT/tce-rvos_amd/lib/ab/libtce_old.so python tools/replay_latency.py --reps 100 2>&1 | grep -v amdgpu
-python tools/replay_latency.py --reps 100 2>&1 | grep -v amdgpu
-TCE_LIB=$GRAFT_REPO_ROOT/tce-rvos_amd/lib/ab/libtce_old.so python tools/replay_latency.py --reps 100 2>&1 | grep -v amdgpu
-python tools/replay_latency.py --reps 100 2>&1 | grep -v amdgpu
+python -m pytest tests -m gpu -x -q > $O/tests_all.log 2>&1 || { tail -40 $O/tests_all.log; exit 1; }
+tail -3 $O/tests_all.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_final.json 2> $O/bench_final.err || { tail -20 $O/bench_final.err; exit 1; }
+python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/r3u/bench_final.json').read().strip().splitlines()[-1])
+print({k:j.get(k) for k in ('value','ms_per_step','value_c2','value_c4','value_text_cached','value_f32_exact')}, j['roofline']['frac'], j['parity']['mask_iou_vs_oracle'])
+PY
