@@ -156,6 +156,12 @@ def lib():
     return _LIB
 
 
+def lib_raw():
+    """The CDLL itself even while hazard.recording() has a recording proxy standing in for it."""
+    l = lib()
+    return l.__dict__.get("_real", l)
+
+
 def check(status, what=""):
     if status != 0:
         msg = lib().tce_last_error().decode(errors="replace")

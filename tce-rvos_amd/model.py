@@ -712,29 +712,61 @@ class ReferFormer(nn.Module):
                         fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
                         fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
+    def _branch_resources(self, like, slot=0):
+        """(arena, side arena, side stream, arena2, stream2, arena3, stream3, arena4, stream4) of one capture: the main arena
+        and one arena per parallel branch that allocates; the side streams are the (device, slot)'s shared set."""
+        T, _, H0, W0 = like.shape
+        tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
+        st = _side_streams(like.device, slot)
+        return (ops.Arena(like.device, self._arena_bytes(T, H0, W0)),
+                ops.Arena(like.device, T * self._tokens_per_frame(H0, W0) * 256 * 4 * 4 + (32 << 20)),
+                st[0],
+                # third branch: the pixel decoder's stride-4 lateral path (tgt + its self-attention / FFN temporaries)
+                ops.Arena(like.device, int(tok0 * 4 * (2048 * 1.1 + 256 * 4)) + (64 << 20)),
+                st[1],
+                # fourth / fifth branch: the stride-32 lateral path + the merge chain down to stride 16 (tokens/64 and
+                # tokens/16 maps, two-GEMM FFN hidden [tokens/16 ... , 2048]); the stride-16 lateral path.  With the early
+                # input projections the fourth also hosts encoder level 0 (tokens/4 rows): sized for its UNFUSED form
+                # (projection, GroupNorm output, q, attention output + workspaces: 5 maps of [tokens/4, 256]) -- the form
+                # exact-fp32 mode and captions longer than 32 tokens take (ADVICE r2)
+                ops.Arena(like.device, max(int(tok0 / 64 * 4 * (2048 + 256 * 12)) + int(tok0 / 16 * 4 * 256 * 8),
+                                           int(tok0 / 4 * 4 * 256 * 5)) + (64 << 20)),
+                st[2],
+                ops.Arena(like.device, int(tok0 / 16 * 4 * (2048 * 1.1 + 256 * 12)) + (64 << 20)),
+                st[3])
+
+    @torch.no_grad()
+    def hazard_check(self, frames, ids, img_hw=None, valid=None, slot=0, dry=False):
+        """Records ONE pass of the clip's launch program on the capture topology (the same arenas, side streams, forks and
+        joins a captured graph is built from) and checks it for races: any two launches not ordered by a fork / join edge
+        must touch disjoint memory (tce_rvos_amd/hazard.py).  frames [T,3,H,W] and token ids [1,L] on the GPU.
+        dry=True: the recorded pass launches nothing (negative controls).  Returns a hazard.Report (`.clean`, `str()`);
+        results of the pass are discarded."""
+        from . import hazard
+        frames = frames.to(torch.float32).contiguous()
+        T, _, H0, W0 = frames.shape
+        img_h, img_w = (float(H0), float(W0)) if img_hw is None else (float(img_hw[0]), float(img_hw[1]))
+        self._ensure_packed()
+        res = self._branch_resources(frames, slot)
+        st = (frames.clone(), ids.to(frames.device).clone())
+        run = lambda: self._run(st[0], lambda alloc: self._text_plan().forward(st[1], alloc), img_h, img_w, res, valid=valid)  # noqa: E731
+        main = torch.cuda.Stream(device=frames.device)  # like a capture: never the legacy default stream (it syncs with all)
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            if not dry:  # warm-up: per-shape constants and lazy initialisations (host syncs) happen here, not in the record
+                run()
+            torch.cuda.synchronize()
+            with hazard.recording(dry=dry) as rec:
+                run()
+            torch.cuda.synchronize()
+        torch.cuda.current_stream().wait_stream(main)
+        return rec.analyse()
+
     def _capture(self, key, statics, fn, like, slot=0):
         """Captures fn((arena, side_arena, side_stream, ...)) into a graph; the arenas belong to the graph (their
         addresses are baked into it), the side streams are the (device, slot)'s shared set.  Returns None (and pins the
         key to the eager path) if a branch arena turns out too small for this shape's kernels."""
-        T, _, H0, W0 = like.shape
-        tok0 = T * ((H0 + 3) // 4) * ((W0 + 3) // 4)
-        st = _side_streams(like.device, slot)
-        res = (ops.Arena(like.device, self._arena_bytes(T, H0, W0)),
-               ops.Arena(like.device, T * self._tokens_per_frame(H0, W0) * 256 * 4 * 4 + (32 << 20)),
-               st[0],
-               # third branch: the pixel decoder's stride-4 lateral path (tgt + its self-attention / FFN temporaries)
-               ops.Arena(like.device, int(tok0 * 4 * (2048 * 1.1 + 256 * 4)) + (64 << 20)),
-               st[1],
-               # fourth / fifth branch: the stride-32 lateral path + the merge chain down to stride 16 (tokens/64 and
-               # tokens/16 maps, two-GEMM FFN hidden [tokens/16 ... , 2048]); the stride-16 lateral path.  With the early
-               # input projections the fourth also hosts encoder level 0 (tokens/4 rows): sized for its UNFUSED form
-               # (projection, GroupNorm output, q, attention output + workspaces: 5 maps of [tokens/4, 256]) -- the form
-               # exact-fp32 mode and captions longer than 32 tokens take (ADVICE r2)
-               ops.Arena(like.device, max(int(tok0 / 64 * 4 * (2048 + 256 * 12)) + int(tok0 / 16 * 4 * 256 * 8),
-                                          int(tok0 / 4 * 4 * 256 * 5)) + (64 << 20)),
-               st[2],
-               ops.Arena(like.device, int(tok0 / 16 * 4 * (2048 * 1.1 + 256 * 12)) + (64 << 20)),
-               st[3])
+        res = self._branch_resources(like, slot)
         try:
             fn(res)  # eager warm-up on the same resources: builds per-shape constants, lazy inits
         except MemoryError as e:

@@ -725,3 +725,48 @@ def test_padded_clip_matches_oracle(models, backbone):
     bad[0, :, 10:20, 10:20] = True
     with pytest.raises(NotImplementedError):
         model(NestedTensor(nt.tensors, bad), ids, tgt)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The launch program itself: race-free by construction (tce_rvos_amd/hazard.py; VERDICT r3 "next round" #1)
+# ---------------------------------------------------------------------------------------------------------------------
+def _hazard(model, T, H, W, L=32, valid=None, dry=False):
+    frames = synth_frames(T, H, W, 11).cuda()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, 50000, (1, L), generator=g).cuda()
+    return model.hazard_check(frames, ids, (H, W), valid=valid, dry=dry)
+
+
+@pytest.mark.parametrize("backbone,T,H,W", [("swin_t_p4w7", 3, 96, 132),       # small: every fallback (un-fused) form
+                                            ("swin_t_p4w7", 5, 360, 640),      # BASELINE config 2: the fused forms
+                                            ("video_swin_t_p4w7", 8, 384, 640),  # BASELINE config 3
+                                            ("resnet50", 1, 360, 640)])        # BASELINE config 1
+def test_launch_program_is_race_free(models, backbone, T, H, W):
+    """One pass of the clip's launch program on the capture topology (6 streams, 5 arenas) is recorded -- every launch with
+    the byte ranges it reads / writes, every fork / join edge -- and any two launches not ordered by happens-before must
+    touch disjoint memory.  Needs no timing luck: what a captured graph may run concurrently is exactly what is compared."""
+    rep = _hazard(models(backbone, 5), T, H, W)
+    print(rep)
+    assert rep.launches > 200 and rep.streams >= 4 and rep.unordered_pairs > 1000  # the program really forked
+    assert rep.clean, str(rep)
+
+
+def test_launch_program_race_free_padded_and_long_caption(models):
+    m = models("swin_t_p4w7", 5)
+    rep = _hazard(m, 3, 96, 160, valid=(90, 140))  # padded clip: valid-region kernels, key-padding masks
+    assert rep.clean, str(rep)
+    rep = _hazard(m, 2, 64, 96, L=40)  # > 32 tokens: the un-folded cross-attention forms
+    assert rep.clean, str(rep)
+
+
+def test_hazard_checker_sees_a_dropped_join(models, monkeypatch):
+    """Negative control on the real program: with every join of the fork / join topology dropped, the checker must report
+    conflicts (the text branch's keys, the level slices' consumers, the decoder's outputs ...)."""
+    from tce_rvos_amd import pipeline
+    m = models("swin_t_p4w7", 5)
+    assert _hazard(m, 3, 96, 132).clean  # (warms the per-shape constants up with the real program)
+    monkeypatch.setattr(pipeline._Fork, "join", lambda self: None)
+    rep = _hazard(m, 3, 96, 132, dry=True)  # recorded only: the broken program is never launched
+    torch.cuda.synchronize()
+    print(rep)
+    assert not rep.clean and rep.n_conflicts > 10
