@@ -97,6 +97,12 @@ def main():
                     help="gloo (+ TCE_BENCH_ONE_DEVICE=1: every rank on cuda:0) rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent B=1 clip forwards kept in flight per GPU and per step (one stream + replay slot each)")
+    ap.add_argument("--ranks-per-gpu", type=int, default=1,
+                    help="processes sharing one GPU (rank r runs on cuda:(LOCAL_RANK // R)): each process has its own HIP "
+                         "hardware queues, which one process's graph replays do not (DESIGN.md section 6)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1 without the per-step mask all-gather (barrier + max-over-ranks timing only): isolates the "
+                         "compute side of a ranks-per-GPU measurement from gloo's host-side copies")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,13 +119,23 @@ def main():
 
     if os.environ.get("TCE_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    local_rank //= max(1, args.ranks_per_gpu)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TCE_BENCH_FORCE_DIST=1: a world of ONE still initialises the process group and sends every step's masks through the
+    # collective (RCCL's all_gather_into_tensor on device tensors, the barrier, the max-over-ranks all_reduce): the N > 1 code
+    # path executed on a one-GPU box.  Ranks sharing a GPU cannot use RCCL (one communicator per device): they meet over gloo.
+    force_dist = os.environ.get("TCE_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
+    if args.ranks_per_gpu > 1 and args.backend == "nccl" and world > 1:
+        raise SystemExit("--ranks-per-gpu > 1 needs --backend gloo (RCCL allows one rank per device in a communicator)")
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks_async
@@ -144,6 +160,7 @@ def main():
     ids = ids_host.to(dev)
     targets = [{"size": torch.tensor([H, W])}]
     gather_buf, pending = None, None
+    last_local = [None]  # this rank's masks of the last gathered step (the forced world-1 run checks the collective's result)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(C, 4))]
     use_host_ids = False  # the text-cache pass keys the cache on host ids
 
@@ -164,14 +181,15 @@ def main():
                     outs.append(one(i * C + c, slot=c))
             for c in range(C):
                 cur.wait_stream(streams[c])
-        if world > 1 and gather:
+        if dist_on and gather and not args.no_gather:
             # what meets on every rank is what the callers keep: the harness's uint8 masks (inference_ytvos.py:238-250
             # on the GPU), 4x fewer bytes than the fp32 logits.  The collective of step i runs on RCCL's stream while
             # step i+1 computes, and is completed (stream-ordered) before step i+1's own gather starts.
             local = torch.stack([ops.select_masks(o["pred_logits"][0], o["pred_masks"][0], (H, W))[0] for o in outs], 0)
             if pending is not None:
                 gather_buf = pending.wait()
-            pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C)
+            pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C, force=force_dist)
+            last_local[0] = local
         return outs[0]
 
     def fence():
@@ -179,7 +197,7 @@ def main():
         if pending is not None:  # the last step's masks must have met inside the timed region
             gather_buf = pending.wait()
             pending = None
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -194,7 +212,17 @@ def main():
         return time.perf_counter() - t0
 
     elapsed = timed(args.steps, args.warmup)
-    if world > 1:
+    collective = None
+    if dist_on and not args.no_gather:
+        # the last step's gathered masks must hold this rank's block at this rank's place (checked on every rank)
+        lo = rank * C
+        ok = gather_buf is not None and bool((gather_buf[lo:lo + C].to(last_local[0].device) == last_local[0]).all())
+        collective = {"backend": dist.get_backend(), "world": world, "forced_world1": bool(force_dist and world == 1),
+                      "bytes_per_rank_per_step": int(last_local[0].numel() * last_local[0].element_size()),
+                      "gathered_shape": list(gather_buf.shape), "own_block_matches": ok}
+        if not ok:
+            raise SystemExit(f"bench.py: rank {rank}: the gathered masks do not hold this rank's block")
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -202,7 +230,7 @@ def main():
 
     roofline, roofline_hbm = None, None
     C_saved, C = C, 1  # the instrumented pass, the variants and the parity check run one clip at a time
-    solo = rank == 0 and world == 1
+    solo = rank == 0 and world == 1 and not force_dist
     if rank == 0 and not args.no_roofline:
         n_inst = min(args.steps, 40)
         graph_mode, model.use_graph = model.use_graph, False  # per-launch events need eager launches
@@ -339,7 +367,7 @@ def main():
         metric = METRIC if cfg_name == "BASELINE config 2" else \
             f"clips/s (T={T}, {H}×{W}, {args.backbone}; {cfg_name}) at {world} MI355X; mask IoU vs ref"
         clips_total = args.steps * world * C
-        line = {"metric": metric, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+        line = {"metric": metric, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": (world + args.ranks_per_gpu - 1) // args.ranks_per_gpu,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "timed_region_s": round(elapsed, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -351,14 +379,17 @@ def main():
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
                            "clips_per_step": world * C, "clips_in_flight_per_gpu": C,
+                           "ranks_per_gpu": args.ranks_per_gpu,
                            "parallelism": f"clip-sharded x{world}" +
-                                          (" + harness kernel + RCCL all_gather(uint8 masks)" if world > 1 else "")},
+                                          ((" + harness kernel + " + ("RCCL" if args.backend == "nccl" else "gloo") +
+                                            " all_gather(uint8 masks)") if dist_on else "")},
+                "collective": collective,
                 "launch": "hipGraph replay" if model.use_graph else "eager",
                 "graphs": model.graph_state(),
                 "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity}
         line.update(variants)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()  # rank 0's extra (collective-free) passes are done: leave together
         dist.destroy_process_group()
 

@@ -166,6 +166,15 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
     slabs += tce_cdiv(g.N, FR_COLS);
   }
   TCE_CHECK_ARG(!a->res || a->ldres >= a->seg[0].N, "tce_fewrow_linear_f32: residual pitch");
+#ifdef FEWROW_RPT2
+  // The removed 64-row-per-workgroup dispatch of the round-3 incident, kept compilable for audit only:
+  //   HIPCC_EXTRA=-DFEWROW_RPT2 python -m tce_rvos_amd.build --force.  Never part of the shipped library.
+  if (a->R > 32 && a->R <= 64) {
+    hipLaunchKernelGGL(fewrow_linear_kernel<2>, dim3(slabs, 1), dim3(256), 0, (hipStream_t)stream, p);
+    TCE_CHECK_LAUNCH("tce_fewrow_linear_f32");
+    return TCE_OK;
+  }
+#endif
   hipLaunchKernelGGL(fewrow_linear_kernel<1>, dim3(slabs, tce_cdiv(a->R, 32)), dim3(256), 0, (hipStream_t)stream, p);
   TCE_CHECK_LAUNCH("tce_fewrow_linear_f32");
   return TCE_OK;

@@ -6,10 +6,22 @@ clips and the per-clip mask logits meet through ONE collective per batch: an all
 (`torch.distributed` backend "nccl" on ROCm).  No other data-path collective exists on this path.
 The same code runs on the gloo backend (CPU tensors) for the world_size-2 tests.
 """
+import os
 from typing import List, Tuple
 
 import torch
 import torch.distributed as dist
+
+# TCE_DIST_FORCE=1 (or force=True): run the collective even in a group of ONE rank.  A world of one normally short-cuts
+# (nothing to gather); forcing it sends the same tensors through the same RCCL entry points a multi-GPU job uses -- the
+# only way to execute the RCCL path on a one-GPU box (tests/test_e2e_gpu.py::test_rccl_world1_*).
+FORCE_COLLECTIVE = os.environ.get("TCE_DIST_FORCE") == "1"
+
+
+def _skip_collective(group, force):
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not (force or FORCE_COLLECTIVE)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -19,11 +31,11 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_clip_masks(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+def gather_clip_masks(local: torch.Tensor, n_total: int, group=None, force: bool = False) -> torch.Tensor:
     """local [n_local, ...] (this rank's clips, in clip order) -> [n_total, ...] on every rank, in global clip order.
     Ranks may hold different clip counts (n_total % world != 0): shards are padded to the largest count for the
     collective and trimmed after."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip_collective(group, force):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
@@ -64,9 +76,9 @@ class PendingGather:
         return torch.cat([out[r, :counts[r]] for r in range(len(counts))], 0)
 
 
-def gather_clip_masks_async(local: torch.Tensor, n_total: int, group=None) -> PendingGather:
+def gather_clip_masks_async(local: torch.Tensor, n_total: int, group=None, force: bool = False) -> PendingGather:
     """Non-blocking form of gather_clip_masks for equal or ragged shards (RCCL / gloo)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip_collective(group, force):
         return PendingGather(None, local[None], [local.shape[0]], None)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
