@@ -56,7 +56,7 @@ int tce_gemm_f32(const tceGemmArgs* args, tceStream stream);
  * GEMMs and (split-fp16 mode) implicit-GEMM convolutions; K % (splits*32) == 0, N % 4 == 0. */
 int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, float* workspace, tceStream stream);
 /* The same with the LayerNorm of a post-norm block folded into the reduction pass: C = LayerNorm(A W^T + bias (+ res)) * gamma
- * + beta (act 0, res_mode 0 or 1, N <= 1024, 16-byte aligned rows).  RoBERTa's attention.output / output sub-layers
+ * + beta (act 0, res_mode 0 or 1, N <= 1024, 16-byte aligned rows).  res may alias C (in place on the residual stream).  RoBERTa's attention.output / output sub-layers
  * (transformers' RobertaSelfOutput / RobertaOutput: dense -> dropout -> LayerNorm(hidden + input)), the decoder FFN's
  * linear2 + norm3 (tce_deformable_transformer.py:548-552). */
 int tce_gemm_splitk_ln_f32(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma, const float* beta,
@@ -71,6 +71,10 @@ int tce_gemm_select_tile_ex(int32_t M, int32_t N, int32_t K, int32_t batch, int3
  * tce_rowlin_pack_f32 carry the rounding of the mode they were packed in: re-pack after switching. */
 int tce_set_gemm_mode(int32_t mode);
 int tce_get_gemm_mode(void);
+/* Per-THREAD override of the mode (-1 = none: the process default applies).  The mode is read when a launch is issued, so a
+ * host thread that switches arithmetic around groups of launches (per-site policies) must not change what another thread's
+ * launches -- or captures -- see.  tce_get_gemm_mode() returns the calling thread's effective mode. */
+int tce_set_gemm_mode_thread(int32_t mode);
 
 /* Operand-range guard of the split-fp16 arithmetic (its operands must lie inside the fp16 range, |x| < 65504: larger
  * values saturate silently in v_cvt_pkrtz).  Weights are checked on the host when they are packed; activations are
@@ -366,8 +370,9 @@ int tce_graph_destroy(void* graph_exec);
  * Few-row linear layers (R of a few dozen rows; csrc/fewrow.hip): up to three projections of the SAME rows in one launch,
  *     out_s[r, n] = act_s( sum_k (x[r,k] (+ a2[r % a2_rows, k] if seg.use_a2)) W_s[n,k] + bias_s[n] )  (+ res[r, n] for s = 0),
  * exact fp32 on the vector ALUs.  act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf).  a2_rows = 0: the addend has one row per x
- * row.  `out` of a segment must not overlap x (rows are re-read by other workgroups); out_0 may alias res (in place on the
- * residual stream).
+ * row.  `out` of a segment must not overlap x or a2 (rows are re-read by other workgroups), the outputs of different segments
+ * must not overlap each other, res must not overlap the outputs of segments 1 / 2; out_0 may alias res exactly (in place on
+ * the residual stream: same pointer, same pitch).  ldx >= K.
  * Replaces the per-token nn.Linear / sigmoid call sites of the frame-token layer, the decoder's per-query projections and
  * the text-side key / value projections (tce_deformable_transformer.py:439-484,665-790; segmentation.py:366-371).
  */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "tce_gemm_select_tile": (i32, [i32, i32, i32]),
     "tce_gemm_select_tile_ex": (i32, [i32, i32, i32, i32, i32]),
     "tce_set_gemm_mode": (i32, [i32]),
+    "tce_set_gemm_mode_thread": (i32, [i32]),
     "tce_set_range_flag": (i32, [c_f]),
     "tce_get_gemm_mode": (i32, []),
     "tce_layernorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, c_f]),
@@ -147,6 +148,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TceError(f"{LIB_PATH} not found: build the HIP extension first "
                            f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+        if hwq not in (None, "", "4"):  # measured, profiles/r03_clip_groups.txt: 1-3 abort the HIP runtime at start-up,
+            import warnings             # 5-16 double the clip time (every graph edge becomes a cross-queue signal)
+            warnings.warn(f"tce_rvos_amd: GPU_MAX_HW_QUEUES={hwq} is set; the HIP runtime's default (4) is the only value this "
+                          f"launch program runs well with (1-3 crash the runtime, 5-16 double the clip time)", RuntimeWarning)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(l, name)  # AttributeError if the symbol is absent

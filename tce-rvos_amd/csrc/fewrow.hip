@@ -140,8 +140,14 @@ __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
 
 extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
   TCE_CHECK_ARG(a && a->x && a->nseg >= 1 && a->nseg <= 3, "tce_fewrow_linear_f32: bad arguments");
-  TCE_CHECK_ARG(a->R > 0 && a->K > 0 && a->K % 4 == 0 && a->ldx % 4 == 0 && tce_aligned16(a->x),
-                "tce_fewrow_linear_f32: K and ldx must be multiples of 4, x 16-byte aligned");
+  TCE_CHECK_ARG(a->R > 0 && a->K > 0 && a->K % 4 == 0 && a->ldx % 4 == 0 && a->ldx >= a->K && tce_aligned16(a->x),
+                "tce_fewrow_linear_f32: K and ldx must be multiples of 4, ldx >= K, x 16-byte aligned");
+  // [begin, end) of a row-strided operand in floats
+  auto span = [&](const float* p, long long ld, long long cols, long long rows, const float*& b, const float*& e) {
+    b = p;
+    e = p + (rows - 1) * ld + cols;
+  };
+  auto disjoint = [](const float* b0, const float* e0, const float* b1, const float* e1) { return e0 <= b1 || e1 <= b0; };
   FrArgs p;
   p.x = a->x; p.a2 = a->a2; p.res = a->res;
   p.ldx = a->ldx; p.lda2 = a->lda2; p.ldres = a->ldres;
@@ -156,10 +162,29 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
                   "tce_fewrow_linear_f32: segment %d: bad weight / output geometry", s);
     TCE_CHECK_ARG(!g.use_a2 || (a->a2 && a->lda2 % 4 == 0 && tce_aligned16(a->a2)), "tce_fewrow_linear_f32: addend missing / misaligned");
     TCE_CHECK_ARG(g.act >= 0 && g.act <= 3, "tce_fewrow_linear_f32: act must be 0 (none), 1 (ReLU), 2 (sigmoid) or 3 (GELU)");
-    {  // every workgroup re-reads the x rows while others store: an output must not overlap them
-      const float *xb = a->x, *xe = a->x + (long long)(a->R - 1) * a->ldx + a->K;
-      const float *ob = g.out, *oe = g.out + (long long)(a->R - 1) * g.ldo + g.N;
-      TCE_CHECK_ARG(oe <= xb || xe <= ob, "tce_fewrow_linear_f32: segment %d: out overlaps x", s);
+    {  // every workgroup re-reads the x (and addend) rows while others store: an output must not overlap them, nor another
+       // segment's output; the residual may only BE segment 0's output (in place), never overlap anything else that is written
+      const float *xb, *xe, *ob, *oe;
+      span(a->x, a->ldx, a->K, a->R, xb, xe);
+      span(g.out, g.ldo, g.N, a->R, ob, oe);
+      TCE_CHECK_ARG(disjoint(xb, xe, ob, oe), "tce_fewrow_linear_f32: segment %d: out overlaps x", s);
+      if (a->a2) {
+        const float *ab, *ae;
+        span(a->a2, a->lda2, a->K, a->a2_rows > 0 ? a->a2_rows : a->R, ab, ae);
+        TCE_CHECK_ARG(disjoint(ab, ae, ob, oe), "tce_fewrow_linear_f32: segment %d: out overlaps a2", s);
+      }
+      for (int t = 0; t < s; ++t) {
+        const float *pb, *pe;
+        span(a->seg[t].out, a->seg[t].ldo, a->seg[t].N, a->R, pb, pe);
+        TCE_CHECK_ARG(disjoint(pb, pe, ob, oe), "tce_fewrow_linear_f32: outputs of segments %d and %d overlap", t, s);
+      }
+      if (a->res) {
+        const float *rb, *re;
+        span(a->res, a->ldres, a->seg[0].N, a->R, rb, re);
+        const bool in_place = s == 0 && a->res == g.out && a->ldres == g.ldo;
+        TCE_CHECK_ARG(in_place || disjoint(rb, re, ob, oe),
+                      "tce_fewrow_linear_f32: segment %d: res overlaps out (only segment 0 may alias it, exactly)", s);
+      }
     }
     d.W = g.W; d.bias = g.bias; d.out = g.out; d.N = g.N; d.ldw = g.ldw; d.ldo = g.ldo; d.use_a2 = g.use_a2; d.act = g.act;
     d.slab0 = slabs;

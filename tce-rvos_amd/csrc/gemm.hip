@@ -197,12 +197,23 @@ int tce_gemm_f16x3_launch_small(const tceGemmArgs& a, int tile, hipStream_t s); 
 
 // 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: 3 x fp16 split MFMA (fp32-accurate);
 // 2: single fp16 MFMA per product, operands rounded to nearest fp16, fp32 accumulate (BASELINE config 5's arithmetic)
-static int g_gemm_mode = 1;
+// The process default (tce_set_gemm_mode) and a per-THREAD override (tce_set_gemm_mode_thread; -1 = none): per-site
+// arithmetic switches the mode dozens of times per clip around groups of launches, and the mode is read when a launch is
+// ISSUED -- with one process-wide variable a second host thread issuing launches meanwhile would run (or capture) the
+// wrong arithmetic silently.  A thread's switches are now its own.
+static int g_gemm_mode_default = 1;
+static thread_local int t_gemm_mode = -1;
+#define g_gemm_mode (t_gemm_mode >= 0 ? t_gemm_mode : g_gemm_mode_default)
 int tce_gemm_single_pass() { return g_gemm_mode == 2; }
 
 extern "C" int tce_set_gemm_mode(int32_t mode) {
   TCE_CHECK_ARG(mode >= 0 && mode <= 2, "tce_set_gemm_mode: mode must be 0 (f32), 1 (3xf16 split) or 2 (single f16)");
-  g_gemm_mode = mode;
+  g_gemm_mode_default = mode;
+  return TCE_OK;
+}
+extern "C" int tce_set_gemm_mode_thread(int32_t mode) {
+  TCE_CHECK_ARG(mode >= -1 && mode <= 2, "tce_set_gemm_mode_thread: mode must be -1 (no override), 0, 1 or 2");
+  t_gemm_mode = mode;
   return TCE_OK;
 }
 extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
@@ -359,8 +370,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // The same reduction with the LayerNorm that follows it in every post-norm block (RoBERTa's attention.output / output
 // sub-layers, the decoder's FFN): one wavefront per output row (N <= 1024) sums the splits, adds bias + residual and
 // normalises the row -- the LayerNorm launch behind a split-K GEMM disappears (24 per clip in the text encoder alone).
+// res may alias C (every caller runs it in place on the residual stream): neither is __restrict__, and a row's residual
+// is fully read (it feeds the mean) before the row's first store -- one wavefront owns the row.
 __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                               const float* __restrict__ res, float* __restrict__ C,
+                                                               const float* res, float* C,
                                                                const int M, const int N, const int splits, const int ldc,
                                                                const int ldres, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float eps) {

@@ -339,7 +339,7 @@ MODELS = {
     "tce_fewrow_linear_f32": lambda a: _fewrow(_st(a[0])),
 }
 # Entry points that launch nothing (queries, process switches, graph helpers, tuning aids): passed through.
-NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode",
+NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode", "tce_set_gemm_mode_thread",
                 "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes",
                 "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
                 "tce_graph_destroy"} | set(_lib.DEBUG_SIGNATURES)

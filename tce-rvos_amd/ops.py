@@ -3,6 +3,7 @@ arithmetic stage is a HIP kernel of libtce_rvos.so.  No op here has a PyTorch fa
 import ctypes as C
 
 import os
+import threading
 
 import torch
 
@@ -85,28 +86,35 @@ def set_gemm_mode(mode):
 
 
 def get_gemm_mode():
+    """The calling thread's effective mode: its `arith` override if one is active, else the process default."""
     return {0: "f32", 1: "f16x3", 2: "f16"}[lib().tce_get_gemm_mode()]
 
 
+_ARITH_TL = threading.local()
+
+
 class arith:
-    """`with ops.arith("f16"):` -- the launches (and weight packs) inside run in that arithmetic; None = leave the
-    process mode alone.  The mode is read on the host when a launch is issued (it is an argument of the kernels), so
-    a captured hipGraph keeps, per node, the mode that was current at capture: this is how one clip mixes single-pass
-    fp16 sites with split-fp16 ones (model.arith_policy, BASELINE config 5)."""
+    """`with ops.arith("f16"):` -- the launches (and weight packs) inside run in that arithmetic; None = leave the mode
+    alone.  The mode is read on the host when a launch is issued (it is an argument of the kernels), so a captured
+    hipGraph keeps, per node, the mode that was current at capture: this is how one clip mixes single-pass fp16 sites with
+    split-fp16 ones (model.arith_policy, BASELINE config 5).  The override is per THREAD (tce_set_gemm_mode_thread): another
+    host thread issuing launches meanwhile keeps its own arithmetic; set_gemm_mode sets the process default."""
 
     def __init__(self, mode):
         self.mode, self.prev = mode, None
 
     def __enter__(self):
         if self.mode is not None:
-            self.prev = get_gemm_mode()
-            if self.prev != self.mode:
-                set_gemm_mode(self.mode)
+            self.prev = getattr(_ARITH_TL, "mode", None)
+            _ARITH_TL.mode = self.mode
+            check(lib().tce_set_gemm_mode_thread({"f32": 0, "f16x3": 1, "f16": 2}[self.mode]), "tce_set_gemm_mode_thread")
         return self
 
     def __exit__(self, *exc):
-        if self.mode is not None and self.prev != self.mode:
-            set_gemm_mode(self.prev)
+        if self.mode is not None:
+            _ARITH_TL.mode = self.prev
+            check(lib().tce_set_gemm_mode_thread(-1 if self.prev is None else {"f32": 0, "f16x3": 1, "f16": 2}[self.prev]),
+                  "tce_set_gemm_mode_thread")
         return False
 
 

@@ -37,9 +37,28 @@ def _lin(A, x, M, K, w, b, N, **kw):
     return out
 
 
-# Diagnostic (tools/ablate_times.py): stages named in TCE_ABLATE are SKIPPED -- results are then garbage; the time that
-# disappears is the stage's share of the clip's critical path (what optimising it to zero would buy).
+# Environment switches of the launch program, read ONCE at import: they are constants of the process, so every capture of
+# the process is built from the same program (none of them needs to be part of a graph key).
+#   scheduling A/B switches (results identical): TCE_FEWROW, TCE_TEXT_LATE, TCE_EARLY_PROJ, TCE_TOKFORK, TCE_ENCFORK,
+#       TCE_LAT1_AT; TCE_FEWROW_SITES (bisect aid: which sites take the few-row kernel)
+#   DIAGNOSTICS that change what forward() returns -- set by tools/ only, announced with a warning at import:
+#       TCE_ABLATE (tools/ablate_times.py): the named stages are SKIPPED, results are garbage (the time that disappears is
+#           the stage's share of the critical path); the output dict carries out["ablated"];
+#       TCE_TAPS=1 (tools/graph_vs_eager.py): copies of intermediates ride out in out["taps"].
 ABLATE = set(filter(None, os.environ.get("TCE_ABLATE", "").split(",")))
+TAPS = os.environ.get("TCE_TAPS") == "1"
+FEWROW_OK = os.environ.get("TCE_FEWROW", "1") != "0"
+FEWROW_SITES = os.environ["TCE_FEWROW_SITES"].split(",") if "TCE_FEWROW_SITES" in os.environ else None
+TEXT_LATE = os.environ.get("TCE_TEXT_LATE", "1") != "0"
+EARLY_PROJ = os.environ.get("TCE_EARLY_PROJ", "1") != "0"
+TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
+ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
+LAT1_AT = os.environ.get("TCE_LAT1_AT")
+if ABLATE or TAPS:
+    import warnings
+    warnings.warn(f"tce_rvos_amd: DIAGNOSTIC launch program (TCE_ABLATE={sorted(ABLATE)}, TCE_TAPS={int(TAPS)}): "
+                  + ("stages are skipped, every result of this process is GARBAGE" if ABLATE else "intermediates are copied out"),
+                  RuntimeWarning, stacklevel=2)
 
 
 # Diagnostic: when set to a list, run_clip appends (stage name, event recorded on the main stream at the END of the
@@ -114,15 +133,12 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # that serve several projections of the same rows at once (TCE_FEWROW=0: tiled GEMMs).  The LayerNorms stay launches of
     # their own: finishing rows in "the last workgroup" needs an agent-scope release / acquire, on this 8-XCD part an L2
     # write-back + invalidate -- 19 us, more than the launch it would save (profiles/r03_fewrow.txt).
-    few_ok = os.environ.get("TCE_FEWROW", "1") != "0"
     FR = ops.fewrow_linear
 
-    few_sites = os.environ.get("TCE_FEWROW_SITES")  # bisect aid: comma list of msda,ftf2,ftf3,dec,text (default: all)
-
-    def few(rows, site=None):
-        if few_sites is not None and site not in few_sites.split(","):
+    def few(rows, site=None):  # TCE_FEWROW_SITES: comma list of msda,ftf2,ftf3,dec,text (default: all)
+        if FEWROW_SITES is not None and site not in FEWROW_SITES:
             return False
-        return few_ok and rows <= ops.FEWROW_MAX_ROWS
+        return FEWROW_OK and rows <= ops.FEWROW_MAX_ROWS
 
     # ------------------------------------------------------------------ text stage (tce_rvos.py:406-424, FeatureResizer
     # :616-635) and everything that depends on the text alone: the projected keys / values of the five text
@@ -173,7 +189,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # Capture order = submission order of a replay (the graph's nodes are enqueued in the order they were captured): the ~140
     # few-microsecond launches of the text branch go in AFTER the first Swin stage's, so the backbone (the critical path)
     # does not queue behind them (TCE_TEXT_LATE=0: text first).
-    text_late = os.environ.get("TCE_TEXT_LATE", "1") != "0" and not cfg.is_resnet
+    text_late = TEXT_LATE and not cfg.is_resnet
     if not text_late:
         text_stage()
 
@@ -213,7 +229,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # work on few tokens); the two small ones follow the backbone, each on its own stream.
     chs = cfg.num_channels
     early = (fork3 is not None and not cfg.is_resnet and fork3[0][1] is not None and fork3[1][1] is not None and
-             side_stream is not None and os.environ.get("TCE_EARLY_PROJ", "1") != "0")
+             side_stream is not None and EARLY_PROJ)
     src = A(T * S, D) if early else None  # [T, S, 256]: the encoder sequence
     lvl_forks = []
 
@@ -289,7 +305,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # them, and it must be done when the chain reaches stride 4.  Measured at config 2 (ms per clip): right after Swin
     # stage 0 8.09, after the backbone 7.44, after encoder layer 0 / 1 / 2 / 3 (of 4) 7.41 / 7.37 / 7.27 / 7.71 ->
     # one encoder layer before the end ("backbone" / "encN" override for experiments).
-    lat1_when = os.environ.get("TCE_LAT1_AT", f"enc{cfg.enc_layers - 2}" if cfg.enc_layers >= 2 else "backbone")
+    lat1_when = LAT1_AT or (f"enc{cfg.enc_layers - 2}" if cfg.enc_layers >= 2 else "backbone")
     if ar2 is not None and stream2 is not None and lat1_when == "backbone":
         lat1 = start_lat1()
     # ------------------------------------------------------------------ input_proj + early fusion (:258-307)
@@ -320,7 +336,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
     # free between the text join and the decoder fork
-    tok_stream = side_stream if os.environ.get("TCE_TOKFORK", "1") != "0" else None
+    tok_stream = side_stream if TOKFORK else None
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
              ar=ar, norm=None, small_fork=None, group="encoder.msda"):
@@ -391,7 +407,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     res=resid, ldres=D, res_mode=RES_ADD)
         ar.release(m1)
 
-    taps = {} if os.environ.get("TCE_TAPS") == "1" else None  # bisect aid: copies of intermediates ride out with the outputs
+    taps = {} if TAPS else None  # bisect aid: copies of intermediates ride out with the outputs
 
     tap_pool = A(cfg.enc_layers * (16 * T * max(Fk, 1) * D + 3 * T * S * D)) if taps is not None else None  # persistent (base level)
     tap_off = [0]
@@ -487,7 +503,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             # the offsets|weights projection (src + pos) and the value projection (src) are independent 24100-row GEMMs of 1.1 and
             # 0.74 workgroup rounds: side by side they pack into 1.9 rounds instead of 3 (TCE_ENCFORK=0: one after the other)
             msda(lp + "self_attn.", src, T * S, S, lvl_pos, True, src, enc_ref, 2, False, src, norm=lp + "norm1",
-                 small_fork=_Fork(tok_stream) if os.environ.get("TCE_ENCFORK", "1") != "0" else None)
+                 small_fork=_Fork(tok_stream) if ENCFORK else None)
         ffn(src, T * S, lp, norm=lp + "norm2")
         tap(f"L{i}.src6", src)
         if ar2 is not None and stream2 is not None and lat1_when == f"enc{i}":
@@ -635,6 +651,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     out["memory"] = keep(memory.reshape(T, S, D))
     if taps:
         out["taps"] = [{k_: keep(v_) for k_, v_ in taps.items()}]
+    if ABLATE:
+        out["ablated"] = sorted(ABLATE)  # these results are garbage by construction (tools/ablate_times.py)
     ar.release(m0)
     return out
 

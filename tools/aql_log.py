@@ -26,11 +26,12 @@ tgt = [{"size": torch.tensor([H, W])}]
 for _ in range(3):  # eager, capture + first replay, replay
     m([frames], ids, tgt)
 torch.cuda.synchronize()
-log = os.environ["AMD_LOG_LEVEL_FILE"]
-mark = os.path.getsize(log) if os.path.exists(log) else 0
+import glob
+log = max(glob.glob(os.environ["AMD_LOG_LEVEL_FILE"] + "*"), key=os.path.getsize)  # ROCclr appends _<pid>
+mark = os.path.getsize(log)
 m([frames], ids, tgt)   # the replay whose packets are wanted
 torch.cuda.synchronize()
-print("REPLAY_LOG_OFFSET", mark, os.path.getsize(log) if os.path.exists(log) else -1, flush=True)
+print("REPLAY_LOG_OFFSET", mark, os.path.getsize(log), flush=True)
 """
 
 
@@ -60,6 +61,36 @@ def main():
     for c in cands:  # the full log can be hundreds of MB: keep the replay's slice only
         os.remove(c)
     print("replay slice:", len(data), "bytes")
+    print(summarise(data.decode(errors="replace")))
+
+
+def summarise(text):
+    """Histogram of the packets of the slice: kind, barrier bit, acquire / release fence scope (0 none, 1 agent, 2 system),
+    per hardware queue, and the run-length sequence (q<queue><D|B><acquire><release>x<count>)."""
+    import collections
+    import re
+    pat = re.compile(r"HWq=(0x[0-9a-f]+), id=\d+, (\w+) Header = 0x[0-9a-f]+ \(type=\d+, barrier=(\d), acquire=(\d), release=(\d)\)")
+    rows = pat.findall(text)
+    qs = {}
+    out = [f"{len(rows)} AQL packets"]
+    hist = collections.Counter((k, b, a, r) for _, k, b, a, r in rows)
+    for (k, b, a, r), n in sorted(hist.items(), key=lambda kv: -kv[1]):
+        out.append(f"  {k:10s} barrier={b} acquire={a} release={r}: {n}")
+    perq = collections.Counter((qs.setdefault(q, len(qs)), k) for q, k, *_ in rows)
+    out.append("  per hardware queue: " + ", ".join(f"q{q} {k} {n}" for (q, k), n in sorted(perq.items())))
+    seq, prev, n = [], None, 0
+    for q, k, b, a, r in rows:
+        cur = f"q{qs[q]}{k[0]}{a}{r}"
+        if cur == prev:
+            n += 1
+        else:
+            if prev:
+                seq.append(f"{prev}x{n}")
+            prev, n = cur, 1
+    if prev:
+        seq.append(f"{prev}x{n}")
+    out.append("  sequence: " + " ".join(seq))
+    return "\n".join(out)
 
 
 if __name__ == "__main__":
