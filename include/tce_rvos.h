@@ -360,6 +360,23 @@ int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, 
                           float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream);
 int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream);
 
+/* Swin attention half-block as ONE launch (csrc/swinattn.hip):
+ *     out = x + proj( window_attention( LayerNorm_norm1(x) ) )                                   C in {96, 128, 192, 256}
+ * i.e. SwinTransformerBlock.forward up to the first residual (swin_transformer.py:202-249) with WindowAttention.forward
+ * (:127-158): norm1, zero padding to a multiple of 7 AFTER the norm (padded tokens carry q, k, v = bias), cyclic shift,
+ * 7x7 window partition, packed qkv projection, q * 32^-0.5, relative position bias table [169, C/32], the -100 shift mask
+ * of the padded grid (:370-388), softmax, P v, output projection, window reverse / un-shift / crop, + x.  x, out: tokens
+ * [T*H*W, C] with row pitches ldx / ldo; out may BE x (in place: the Swin residual stream) or must not overlap it.
+ * Replaces tce_rowlin_f32 (norm1 -> qkv) + tce_window_attn_f32 + tce_gemm_f32 (proj + residual) and the [tokens, 3C] qkv
+ * tensor between them.  Weights are packed once (tce_swin_attn_pack_f32: Wqkv [3C, C], Wproj [C, C] in nn.Linear layout ->
+ * tce_swin_attn_packed_bytes(C) bytes: fp16 hi/lo planes in the order the kernel consumes them, carrying the rounding of
+ * the GEMM mode they were packed in).  Arithmetic: the library's split-fp16 matrix products (modes 1 and 2). */
+int64_t tce_swin_attn_packed_bytes(int32_t C);
+int tce_swin_attn_pack_f32(const float* Wqkv, const float* Wproj, void* packed, int32_t C, tceStream stream);
+int tce_swin_attn_fused_f32(const float* x, int64_t ldx, const void* packed, const float* qkv_bias, const float* proj_bias,
+                            const float* bias_table, const float* gamma1, const float* beta1, float eps, float* out, int64_t ldo,
+                            int32_t T, int32_t H, int32_t W, int32_t C, int32_t shift, tceStream stream);
+
 /* hipGraph helpers so that the Python host can capture one forward and replay it. */
 int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);

@@ -337,11 +337,19 @@ MODELS = {
          dense(_p(a[3]), a[10] * F)],
         [strided(_p(a[4]), a[10] * F, (a[6] * a[7] * a[8], a[5] * F))]),
     "tce_fewrow_linear_f32": lambda a: _fewrow(_st(a[0])),
+    "tce_swin_attn_pack_f32": lambda a: ([dense(_p(a[0]), 3 * a[3] * a[3] * F), dense(_p(a[1]), a[3] * a[3] * F)],
+                                         [dense(_p(a[2]), _lib.lib_raw().tce_swin_attn_packed_bytes(a[3]))]),
+    # x, ldx, packed, qkv_bias, proj_bias, table, g1, be1, eps, out, ldo, T, H, W, C, shift
+    "tce_swin_attn_fused_f32": lambda a: (
+        [strided(_p(a[0]), a[14] * F, (a[11] * a[12] * a[13], a[1] * F)), dense(_p(a[2]), _lib.lib_raw().tce_swin_attn_packed_bytes(a[14])),
+         dense(_p(a[3]), 3 * a[14] * F), dense(_p(a[4]), a[14] * F), dense(_p(a[5]), 169 * (a[14] // 32) * F),
+         dense(_p(a[6]), a[14] * F), dense(_p(a[7]), a[14] * F)],
+        [strided(_p(a[9]), a[14] * F, (a[11] * a[12] * a[13], a[10] * F))]),
 }
 # Entry points that launch nothing (queries, process switches, graph helpers, tuning aids): passed through.
 NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode", "tce_set_gemm_mode_thread",
                 "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes",
-                "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
+                "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_swin_attn_packed_bytes", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
                 "tce_graph_destroy"} | set(_lib.DEBUG_SIGNATURES)
 
 

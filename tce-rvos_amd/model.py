@@ -401,6 +401,14 @@ class ReferFormer(nn.Module):
                             mode = self.mode_of(arith_group_of(pre + tag))
                             with ops.arith(mode):
                                 w[pre + tag + ":" + mode] = ops.ffn_pack(w1, sd[pre + l1[:-len("weight")] + "bias"].detach(), w2)
+            # Swin attention half-block as one launch (csrc/swinattn.hip): per block, Wqkv | Wproj as one fragment stream
+            if not cfg.is_resnet and not cfg.video and self._stamp[0] != "f32":
+                mode = self.mode_of("backbone.attn")
+                for k in list(sd):
+                    if k.endswith(".attn.qkv.weight") and sd[k].shape[1] in ops.SWIN_FUSED_C:
+                        pre = k[:-len("attn.qkv.weight")]
+                        with ops.arith(mode):
+                            w[pre + "attn:pk:" + mode] = ops.swin_attn_pack(sd[k].detach(), sd[pre + "attn.proj.weight"].detach())
             # token-stationary linear kernel (csrc/chain.hip): packed copies of every eligible weight in THIS model's routes
             # (keyed by address + arithmetic) so ops.gemm_ex can route the shapes where it wins
             for k in list(w):

@@ -405,6 +405,52 @@ def patch_merge_ln(x, gamma, beta, T, H, W, Cn, eps=1e-5, out=None, alloc=None):
     return out, H2, W2
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Swin attention half-block as one launch (csrc/swinattn.hip): x <- x + proj(window_attention(norm1(x)))
+# ---------------------------------------------------------------------------------------------------------------
+SWIN_FUSED_C = (96, 128, 192, 256)
+SWIN_FUSED = os.environ.get("TCE_SWIN_FUSED", "1") != "0"  # A/B: 0 = norm1->qkv, window attention, proj+res as three launches
+
+
+def swin_attn_pack(wqkv, wproj):
+    """Wqkv [3C, C], Wproj [C, C] (nn.Linear layouts) -> the kernel's weight stream, in the CURRENT arithmetic."""
+    _chk(wqkv, "wqkv")
+    _chk(wproj, "wproj")
+    Cn = wproj.shape[0]
+    nbytes = lib().tce_swin_attn_packed_bytes(Cn)
+    if nbytes < 0 or tuple(wqkv.shape) != (3 * Cn, Cn) or tuple(wproj.shape) != (Cn, Cn):
+        raise ValueError(f"swin_attn_pack: unsupported shapes {tuple(wqkv.shape)}, {tuple(wproj.shape)}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=wqkv.device)
+    check(lib().tce_swin_attn_pack_f32(wqkv.contiguous().data_ptr(), wproj.contiguous().data_ptr(), out.data_ptr(), Cn, _stream()),
+          "tce_swin_attn_pack_f32")
+    return out
+
+
+def swin_attn_fused(x, pk, qkv_bias, proj_bias, table, g1, b1, T, H, W, Cn, shift, eps=1e-5, out=None):
+    """out (default: x, in place) = x + proj(window_attention(LayerNorm(x)));  x [T*H*W, C] token-major."""
+    _chk(x, "x")
+    if out is None:
+        out = x
+    ldx = x.stride(0) if x.dim() == 2 else Cn
+    ldo = out.stride(0) if out.dim() == 2 else Cn
+
+    def go():
+        check(lib().tce_swin_attn_fused_f32(x.data_ptr(), ldx, pk.data_ptr(), qkv_bias.data_ptr(), proj_bias.data_ptr(), table.data_ptr(),
+                                            g1.data_ptr(), b1.data_ptr(), eps, out.data_ptr(), ldo, T, H, W, Cn, shift, _stream()),
+              "tce_swin_attn_fused_f32")
+    if GEMM_PROFILE is None:
+        go()
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    nwin = T * ((H + 6) // 7) * ((W + 6) // 7)
+    # algorithmic FLOPs: qkv + proj on the real tokens, scores + AV on 49 x 49 per (window, head)
+    GEMM_PROFILE.append((f"swin_attn_fused_kernel<{Cn}", False, 8.0 * T * H * W * Cn * Cn + 4.0 * nwin * 49 * 49 * Cn, e0, e1))
+    return out
+
+
 if os.environ.get("TCE_MHA_SPLIT", "1") == "0":  # A/B: every attention launch on the exact fp32-MFMA kernel
     lib().tce_debug_mha_set_split(0)
 

@@ -18,6 +18,8 @@ NH = 8
 # Rows from which the fused FFN kernel (one workgroup = 128 tokens x the whole hidden extent, ~150 us at hidden 2048)
 # beats two GEMM launches: it needs about half the chip's CUs busy.
 FFN_FUSED_MIN_ROWS = int(__import__("os").environ.get("TCE_FFN_FUSED_MIN_ROWS", 16000))
+# Tokens from which the one-launch Swin attention half-block (csrc/swinattn.hip: one workgroup per two 7x7 windows) is used
+SWIN_FUSED_MIN_TOKENS = int(os.environ.get("TCE_SWIN_FUSED_MIN_TOKENS", 2000))
 
 
 def _proj_res_ln(x, wt, bias, resid, M, norm_w, norm_b):
@@ -39,7 +41,7 @@ def _lin(A, x, M, K, w, b, N, **kw):
 
 # Environment switches of the launch program, read ONCE at import: they are constants of the process, so every capture of
 # the process is built from the same program (none of them needs to be part of a graph key).
-#   scheduling A/B switches (results identical): TCE_FEWROW, TCE_TEXT_LATE, TCE_EARLY_PROJ, TCE_TOKFORK, TCE_ENCFORK,
+#   scheduling A/B switches (results identical): TCE_FEWROW, TCE_TEXT_LATE, TCE_TEXT_EARLY_EDGE, TCE_EARLY_PROJ, TCE_TOKFORK, TCE_ENCFORK,
 #       TCE_LAT1_AT; TCE_FEWROW_SITES (bisect aid: which sites take the few-row kernel)
 #   DIAGNOSTICS that change what forward() returns -- set by tools/ only, announced with a warning at import:
 #       TCE_ABLATE (tools/ablate_times.py): the named stages are SKIPPED, results are garbage (the time that disappears is
@@ -50,6 +52,7 @@ TAPS = os.environ.get("TCE_TAPS") == "1"
 FEWROW_OK = os.environ.get("TCE_FEWROW", "1") != "0"
 FEWROW_SITES = os.environ["TCE_FEWROW_SITES"].split(",") if "TCE_FEWROW_SITES" in os.environ else None
 TEXT_LATE = os.environ.get("TCE_TEXT_LATE", "1") != "0"
+TEXT_EARLY_EDGE = os.environ.get("TCE_TEXT_EARLY_EDGE", "0") != "0"
 EARLY_PROJ = os.environ.get("TCE_EARLY_PROJ", "1") != "0"
 TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
 ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
@@ -77,13 +80,19 @@ class _Fork:
     """Runs a block of launches on a side stream (inside hipGraph capture this becomes a parallel graph branch);
     without a side stream it degenerates to in-order execution on the current stream."""
 
-    def __init__(self, side_stream):
+    def __init__(self, side_stream, after=None):
+        """after: an event already recorded on the forking stream -- the branch then depends on the work up to THAT point
+        only, not on everything issued before the fork (its nodes are still captured / submitted here, in program order)."""
         self.side = side_stream
+        self.after = after
         self.ctx = None
 
     def __enter__(self):
         if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream())
+            if self.after is not None:
+                self.side.wait_event(self.after)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -145,7 +154,15 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # cross-attention sites and their folded weight streams (csrc/chain.hip, tce_xattn_fused_f32).  With a side stream it
     # is a parallel graph branch beside the backbone; its buffers live in the side arena until the end of the clip.
     tA = (side_arena if side_arena is not None else ar).alloc
-    text_fork = _Fork(side_stream)
+    # The text branch needs nothing the backbone produces.  TCE_TEXT_EARLY_EDGE=1 gives it a graph edge back to the START of
+    # the clip (its nodes still issued after Swin stage 0's), so that it runs beside stage 0 instead of after it -- measured
+    # SLOWER, 8.09 vs 6.90 ms per clip (A/B twice in one gpurun call, profiles/r04_text_early_edge.txt): its ~150 short launches
+    # interleave with stage 0's long ones on the same hardware queues and stretch the critical path.  Off by default.
+    clip_start = None
+    if side_stream is not None and TEXT_EARLY_EDGE:
+        clip_start = torch.cuda.Event()
+        clip_start.record()
+    text_fork = _Fork(side_stream, after=clip_start)
     L = fk = fv = fpk = sent = None
     vl_sites = {}
     text_in = text
@@ -686,24 +703,33 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
         for j in range(depth if f"swin{i}" not in ABLATE else 0):
             p = f"{b}layers.{i}.blocks.{j}."
             m0 = ar.mark()
+            pk_attn = None
+            if ops.SWIN_FUSED and not cfg.video and ntok >= SWIN_FUSED_MIN_TOKENS:
+                pk_attn = w.get(p + "attn:pk:" + model.mode_of("backbone.attn"))
+            if pk_attn is not None:  # norm1 -> qkv -> window attention -> proj -> + x in ONE launch, in place on x
+                with model.arith("backbone.attn"):
+                    ops.swin_attn_fused(x, pk_attn, w[p + "attn.qkv.bias"], w[p + "attn.proj.bias"],
+                                        w[p + "attn.relative_position_bias_table"], w[p + "norm1.weight"], w[p + "norm1.bias"],
+                                        T, H, W, C, 0 if j % 2 == 0 else cfg.window_size // 2)
             xn = A(ntok, C)
-            with model.arith("backbone.attn"):  # x += proj(window attention(qkv(norm1 x)))
-                qkv = A(ntok, 3 * C)
-                pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
-                if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
-                    ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
-                               ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
-                else:
-                    ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
-                    gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
-                if cfg.video:
-                    att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
-                                            W, C, nH, j % 2 == 1, out=xn)
-                else:
-                    att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
-                                          C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
-                gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
-                        res_mode=RES_ADD)
+            if pk_attn is None:
+                with model.arith("backbone.attn"):  # x += proj(window attention(qkv(norm1 x))) as three launches
+                    qkv = A(ntok, 3 * C)
+                    pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
+                    if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
+                        ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
+                                   ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
+                    else:
+                        ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
+                        gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
+                    if cfg.video:
+                        att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
+                                                W, C, nH, j % 2 == 1, out=xn)
+                    else:
+                        att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
+                                              C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
+                    gemm_ex(att, w[p + "attn.proj.weight"], x, ntok, C, C, C, C, C, bias=w[p + "attn.proj.bias"], res=x, ldres=C,
+                            res_mode=RES_ADD)
             with model.arith("backbone.mlp"):  # x += fc2(GELU(fc1(norm2 x)))
                 pk = w.get(p + "mlp.ffn:pk:" + ops.get_gemm_mode()) if ops.get_gemm_mode() != "f32" else None
                 if pk is not None and ntok >= FFN_FUSED_MIN_ROWS:  # norm2 -> fc1 -> GELU -> fc2 -> +x in one launch

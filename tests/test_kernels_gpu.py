@@ -206,6 +206,77 @@ def test_window_attention(ops, T, H, W, nH, shift):
     close(out2, ref, 1e-4, 1e-4)
 
 
+def _swin_half_ref(x, sd, T, H, W, nH, shift):
+    """x + proj(window_attention(norm1(x))) from the oracle's SwinTransformerBlock (pinned to the reference by the e2e
+    fixtures): the block with an MLP whose second layer is zero."""
+    C = x.shape[-1]
+    full = dict(sd)
+    full.update({"norm2.weight": torch.ones(C), "norm2.bias": torch.zeros(C), "mlp.fc1.weight": torch.zeros(4 * C, C),
+                 "mlp.fc1.bias": torch.zeros(4 * C), "mlp.fc2.weight": torch.zeros(C, 4 * C), "mlp.fc2.bias": torch.zeros(C)})
+    Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+    am = O.shift_attn_mask(Hp, Wp, 7, 3) if shift else None
+    return O.swin_block(full, "", x.view(T, H * W, C), H, W, nH, 7, shift, am).reshape(T * H * W, C)
+
+
+@pytest.mark.parametrize("T,H,W,C,shift", [(2, 18, 25, 96, 0), (2, 18, 25, 96, 3),    # ragged in both dims, two frames
+                                            (1, 9, 13, 192, 3), (1, 7, 7, 128, 3),      # one window per dim: every mask region
+                                            (1, 14, 21, 256, 0), (3, 5, 7, 128, 3),     # fewer rows than a window
+                                            (1, 23, 40, 256, 3), (3, 45, 80, 192, 3),   # config 2's stage-1 / stage-2 maps
+                                            (1, 13, 9, 96, 3)])                         # an odd number of windows (idle window slot)
+def test_swin_attn_fused(ops, T, H, W, C, shift):
+    """The one-launch Swin attention half-block (csrc/swinattn.hip) against the oracle's SwinTransformerBlock: norm1, padding
+    after the norm, cyclic shift, windows, qkv, bias table, -100 mask, softmax, AV, proj, residual -- shifted / padded /
+    ragged cases, in place and out of place (bit-identical), the single-pass fp16 mode's error class."""
+    g = torch.Generator().manual_seed(H * W + C + shift)
+    nH = C // 32
+    x = torch.randn(T * H * W, C, generator=g)
+    sd = {"norm1.weight": 1 + 0.1 * torch.randn(C, generator=g), "norm1.bias": 0.1 * torch.randn(C, generator=g),
+          "attn.qkv.weight": torch.randn(3 * C, C, generator=g) / math.sqrt(C), "attn.qkv.bias": torch.randn(3 * C, generator=g) * 0.3,
+          "attn.relative_position_bias_table": torch.randn(169, nH, generator=g),
+          "attn.proj.weight": torch.randn(C, C, generator=g) / math.sqrt(C), "attn.proj.bias": torch.randn(C, generator=g) * 0.2}
+    ref = _swin_half_ref(x, sd, T, H, W, nH, shift)
+    d = {k: dev(v) for k, v in sd.items()}
+    pk = ops.swin_attn_pack(d["attn.qkv.weight"], d["attn.proj.weight"])
+    args = (pk, d["attn.qkv.bias"], d["attn.proj.bias"], d["attn.relative_position_bias_table"], d["norm1.weight"], d["norm1.bias"],
+            T, H, W, C, shift)
+    xd = dev(x)
+    out = torch.full_like(xd, float("nan"))
+    ops.swin_attn_fused(xd, *args, out=out)
+    close(out, ref, 1e-4, 2e-4)
+    assert torch.equal(xd.cpu(), x)                      # out of place: x untouched
+    xin = xd.clone()
+    ops.swin_attn_fused(xin, *args)                      # in place on the residual stream
+    assert torch.equal(xin, out)
+    rel = ((out.cpu().double() - ref.double()).abs().max() / ref.abs().max()).item()
+    assert rel < 2e-5, rel                               # fp32-class (3 x fp16 split)
+    with ops.arith("f16"):
+        pk16 = ops.swin_attn_pack(d["attn.qkv.weight"], d["attn.proj.weight"])
+        out16 = ops.swin_attn_fused(xd, pk16, *args[1:], out=torch.empty_like(xd))
+    d16 = (out16.cpu() - ref).abs().max().item()
+    assert 0 < d16 < 5e-2, d16                           # one fp16 MFMA per product: fp16-class error, not garbage
+    ops.check_range()
+
+
+def test_swin_attn_fused_matches_three_launch_form_at_config2_size(ops):
+    """BASELINE config 2's first Swin stage (5 x 90 x 160 tokens, C = 96, shifted block): the fused launch against the
+    three-launch form it replaces (LayerNorm -> qkv GEMM, window attention kernel, proj GEMM + residual), every row."""
+    T, H, W, C, shift = 5, 90, 160, 96, 3
+    g = torch.Generator().manual_seed(5)
+    x = dev(torch.randn(T * H * W, C, generator=g))
+    wqkv, bqkv = dev(torch.randn(3 * C, C, generator=g) / math.sqrt(C)), dev(torch.randn(3 * C, generator=g) * 0.3)
+    wp, bp = dev(torch.randn(C, C, generator=g) / math.sqrt(C)), dev(torch.randn(C, generator=g) * 0.2)
+    table, g1, b1 = dev(torch.randn(169, 3, generator=g)), dev(1 + 0.1 * torch.randn(C, generator=g)), dev(0.1 * torch.randn(C, generator=g))
+    xn = ops.layernorm(x, g1, b1)
+    qkv = ops.gemm(xn, wqkv, bias=bqkv)
+    att = ops.window_attn(qkv, bqkv, table, T, H, W, C, 3, shift)
+    ref = ops.gemm(att, wp, bias=bp, res=x, res_mode=ops.RES_ADD)
+    out = ops.swin_attn_fused(x, ops.swin_attn_pack(wqkv, wp), bqkv, bp, table, g1, b1, T, H, W, C, shift, out=torch.empty_like(x))
+    torch.cuda.synchronize()
+    d = (out - ref).abs().max().item()
+    print("fused vs three launches: max abs diff", d)
+    assert d < 2e-4
+
+
 @pytest.mark.parametrize("T,H,W,C", [(2, 18, 25, 96), (1, 9, 13, 192), (1, 5, 7, 384), (1, 4, 4, 32)])
 def test_patch_merge_ln(ops, T, H, W, C):
     g = torch.Generator().manual_seed(H + C)
