@@ -268,6 +268,25 @@ int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* wo
 int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int32_t nheads, float scale, tceStream stream);
 int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
 
+/* Thin linear layers as weight STREAMS (csrc/thin.hip): M <= 128 rows against W [N, K] with N % 32 == 0, K % 256 == 0 -- the
+ * dense layers of RoBERTa at 32 tokens (HuggingFace RobertaSelfAttention / RobertaSelfOutput / RobertaIntermediate /
+ * RobertaOutput under tce_rvos.py:406-424).  One launch requests every byte of W once, from K/256 * N/32 workgroups, in one
+ * memory round trip, and leaves K/256 partial planes ws[s][M][N] (s < tce_thin_linear_splits(M, N, K)); the planes meet
+ *   - in tce_splitk_reduce_f32:  C = LN?( epi( sum_s ws[s] + bias ) )  (act / res / res_mode as tce_gemm_f32; gamma != NULL:
+ *     LayerNorm over N of the sum, as tce_gemm_splitk_ln_f32), or
+ *   - in the NEXT consumer's loads: tce_thin_partials_f32 with xsplits > 0 takes its x operand as partial planes
+ *     [xsplits][M][K] + bias_x[K] + act_x (0 none, 1 ReLU, 2 GELU(erf)) of the previous layer (fc1 -> fc2 without a
+ *     reduction launch); tce_mha_small64_splits_f32 reads the packed qkv projection the same way.
+ * Arithmetic: the library's split-fp16 matrix products (GEMM modes 1 / 2; rejected in exact-fp32 mode). */
+int32_t tce_thin_linear_splits(int32_t M, int32_t N, int32_t K); /* K/256, or -1 if the shape is not supported */
+int tce_thin_partials_f32(const float* x, int64_t ldx, int32_t xsplits, const float* bias_x, int32_t act_x, const float* W,
+                          int64_t ldw, float* ws, int32_t M, int32_t N, int32_t K, tceStream stream);
+int tce_splitk_reduce_f32(const float* ws, int32_t splits, int32_t M, int32_t N, const float* bias, int32_t act, const float* res,
+                          int32_t ldres, int32_t res_mode, float* C, int32_t ldc, const float* gamma, const float* beta, float eps,
+                          tceStream stream);
+int tce_mha_small64_splits_f32(const float* qkv_planes, int32_t splits, const float* bias, float* out, int32_t L, int32_t nheads,
+                               float scale, tceStream stream);
+
 /* Fused FFN / MLP, the hidden tensor kept on chip (csrc/chain.hip):
  *     out[M,C] = LN_out?( x + W2 act( W1 LN_in?(x) + b1 ) + b2 )        act 1 ReLU | 2 GELU(erf)
  * One launch replaces linear1 -> ReLU -> linear2 -> +residual -> LayerNorm of the transformer / VisionLanguageBlock

@@ -115,6 +115,10 @@ SIGNATURES = {
     "tce_conv3x3_pack_f32": (i32, [c_f, c_f, i32, i32, c_f]),
     "tce_conv3x3_f32": (i32, [c_f, i64, c_f, c_f, c_f, i64, i32, i32, i32, i32, i32, c_f]),
     "tce_fewrow_linear_f32": (i32, [C.POINTER(FewRowArgs), c_f]),
+    "tce_thin_linear_splits": (i32, [i32, i32, i32]),
+    "tce_thin_partials_f32": (i32, [c_f, i64, i32, c_f, i32, c_f, i64, c_f, i32, i32, i32, c_f]),
+    "tce_splitk_reduce_f32": (i32, [c_f, i32, i32, i32, c_f, i32, c_f, i32, i32, c_f, i32, c_f, c_f, f32, c_f]),
+    "tce_mha_small64_splits_f32": (i32, [c_f, i32, c_f, c_f, i32, i32, f32, c_f]),
     "tce_swin_attn_packed_bytes": (i64, [i32]),
     "tce_swin_attn_pack_f32": (i32, [c_f, c_f, c_f, i32, c_f]),
     "tce_swin_attn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, i32, c_f]),

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
 # slowest first (they gate the parallel build): the GEMM translation units carry one epilogue body per (act, res) combination
 SOURCES = ["chain.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
-           "text.hip", "resnet.hip", "frontend.hip", "fewrow.hip", "swinattn.hip", "capi.hip"]
+           "text.hip", "resnet.hip", "frontend.hip", "fewrow.hip", "swinattn.hip", "thin.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("HIPCC_EXTRA", "").split()  # audit builds only (e.g. -DFEWROW_RPT2); the shipped library has none

@@ -442,6 +442,28 @@ extern "C" int tce_gemm_splitk_f32(const tceGemmArgs* args, int32_t splits, floa
   return splitk_impl(args, splits, workspace, nullptr, nullptr, 0.f, stream);
 }
 
+// The reduction pass alone: C = LN?( epi( sum_s ws[s] + bias ) ) for partial planes produced by tce_thin_partials_f32
+extern "C" int tce_splitk_reduce_f32(const float* ws, int32_t splits, int32_t M, int32_t N, const float* bias, int32_t act,
+                                     const float* res, int32_t ldres, int32_t res_mode, float* C, int32_t ldc, const float* gamma,
+                                     const float* beta, float eps, tceStream stream) {
+  TCE_CHECK_ARG(ws && C && splits >= 1 && splits <= 64 && M > 0 && N > 0 && N % 4 == 0 && ldc >= N, "tce_splitk_reduce_f32: bad arguments");
+  TCE_CHECK_ARG(act >= 0 && act <= 3 && res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || (res && ldres >= N)),
+                "tce_splitk_reduce_f32: bad act / res_mode");
+  TCE_CHECK_ARG(tce_aligned16(ws) && (!bias || tce_aligned16(bias)), "tce_splitk_reduce_f32: ws / bias must be 16-byte aligned");
+  if (gamma) {
+    TCE_CHECK_ARG(beta && act == 0 && res_mode != 2 && N <= 1024 && ldc % 4 == 0 && (res_mode == 0 || ldres % 4 == 0) &&
+                      tce_aligned16(C) && tce_aligned16(gamma) && tce_aligned16(beta) && (res_mode == 0 || tce_aligned16(res)),
+                  "tce_splitk_reduce_f32: LayerNorm form: no activation, additive residual, N <= 1024, 16-byte aligned rows");
+    hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, bias,
+                       res_mode == 1 ? res : nullptr, C, M, N, splits, ldc, ldres, gamma, beta, eps);
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tce_cdiv((long long)M * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, ws, bias,
+                       res, C, M, N, splits, ldc, ldres, act, res_mode);
+  }
+  TCE_CHECK_LAUNCH("tce_splitk_reduce_f32");
+  return TCE_OK;
+}
+
 extern "C" int tce_gemm_splitk_ln_f32(const tceGemmArgs* args, int32_t splits, float* workspace, const float* gamma,
                                       const float* beta, float eps, tceStream stream) {
   TCE_CHECK_ARG(args && gamma && beta, "tce_gemm_splitk_ln_f32: null pointer");

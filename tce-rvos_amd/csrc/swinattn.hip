@@ -35,6 +35,11 @@
 namespace {
 
 constexpr int WS = 7, NTOK = 49;
+// C up to which the kernel is built for TWO workgroups per CU (<= 256 registers, <= 80 KB of LDS: a workgroup's prologue and
+// epilogue latency, and its softmax, then run under the other's MFMAs); tuning aid, see tools/swin_attn_bench.py
+#ifndef SWIN_OCC2_MAXC
+#define SWIN_OCC2_MAXC 128
+#endif
 
 struct SwinArgs {
   const float* x;
@@ -47,6 +52,11 @@ struct SwinArgs {
   float eps;
   int* range_flag;
   int single;
+  // Per key slot of a lane (slot = 16 kt + r <-> key j = 32 kt + crow(r, hf)), for hf = 0 / 1, built on the host:
+  unsigned cj[2][8];    // 32 bytes: jy * 13 + jx  (relative-position index of (query, key) = (iy*13 + ix + 84) - cj)
+  unsigned kvalid[2];   // bit = the key exists (j < 49)
+  unsigned rowhi[2];    // bit = the key's row inside the window is >= 7 - shift (second region of the last window row)
+  unsigned colhi[2];    // the same for columns
 };
 
 __device__ __forceinline__ int crow_(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -80,14 +90,16 @@ template <int C>
 struct SwinCfg {
   static constexpr int KS = C / 16, NTL = C / 32, NH = C / 32;
   static constexpr int HSTEPS = C / 4;             // (hi, lo) fragment pairs per head: 3 KS + 2 NTL
-  static constexpr int G = (C == 96) ? 24 : 16;    // fragment pairs per ring stage
+  static constexpr int G = (C <= SWIN_OCC2_MAXC) ? 8 : 16;    // fragment pairs per ring stage (8: 67 KB of LDS, two workgroups per CU)
+  static constexpr int WG_PER_CU = (C <= SWIN_OCC2_MAXC) ? 2 : 1;
   static constexpr int IPH = HSTEPS / G;           // ring stages per head
   static constexpr int STAGE = G * 2 * PIECE;
   static constexpr int SLOTS = G * 2 / 4;          // DMAs per wave per stage
   static constexpr int EX_OFF = 2 * STAGE;         // K / V exchange: [window slot][K | V][key tile][hi0, lo0, hi1, lo1]
   static constexpr int EX_WIN = 2 * 2 * 4 * PIECE;
-  static constexpr int WT_OFF = EX_OFF + 2 * EX_WIN;
-  static constexpr int SB_OFF = WT_OFF + 4 * WT_BYTES;
+  static constexpr int WT_OFF = EX_OFF;            // the per-wave staging tiles (prologue / epilogue only) alias the exchange area
+  static constexpr int SB_OFF = EX_OFF + 2 * EX_WIN;
+  static_assert(4 * WT_BYTES <= 2 * EX_WIN, "staging tiles must fit the exchange area");
   static constexpr int SB_PITCH = 172;             // floats per head of the relative-position table (169 used)
   static constexpr int QB_OFF = SB_OFF + NH * SB_PITCH * 4;  // qkv bias [3C] floats (read per head with ds_read: no
   static constexpr int LDS = QB_OFF + 3 * C * 4;             // register global loads inside the DMA loop)
@@ -96,7 +108,7 @@ struct SwinCfg {
 };
 
 template <int C>
-__global__ void __launch_bounds__(256, 1) swin_attn_fused_kernel(const SwinArgs p) {
+__global__ void __launch_bounds__(256, SwinCfg<C>::WG_PER_CU) swin_attn_fused_kernel(const SwinArgs p) {
   using K_ = SwinCfg<C>;
   constexpr int KS = K_::KS, NTL = K_::NTL, NH = K_::NH, HSTEPS = K_::HSTEPS, G = K_::G, STAGE = K_::STAGE, SLOTS = K_::SLOTS;
   constexpr int NP = C / 32;
@@ -213,34 +225,24 @@ __global__ void __launch_bounds__(256, 1) swin_attn_fused_kernel(const SwinArgs 
     }
   }
 
-  // ---- this lane's query token and, for each of its 32 key slots (key tile kt, accumulator register r: key index
-  // 32 kt + crow(r, hf)), the relative-position table index and whether the shift mask separates the pair
+  // ---- this lane's query token; per key slot (key tile kt, accumulator register r: key 32 kt + crow(r, hf)) the relative-
+  // position index and the -100 shift mask come from tables the host built (no per-lane index arithmetic):
+  //   index = (iy*13 + ix + 84) - (jy*13 + jx);  the mask separates regions of the padded, shifted grid (swin_transformer.py:
+  //   370-388): only the last window row / column has two (rows < 7 - shift | rows >= 7 - shift), a pair is masked iff the
+  //   query and the key lie on different sides in the row or in the column direction.
   const int qi = min(32 * qt + l31, NTOK - 1);
   const int iy = qi / WS, ix = qi % WS;
-  auto region = [&](int j) {  // region id on the padded, shifted grid (swin_transformer.py:370-388)
-    const int yy = wy * WS + j / WS, xx = wx * WS + j % WS;
-    const int ry = yy < Hp - WS ? 0 : (yy < Hp - p.shift ? 1 : 2);
-    const int rx = xx < Wp - WS ? 0 : (xx < Wp - p.shift ? 1 : 2);
-    return ry * 3 + rx;
-  };
-  const int rid = p.shift > 0 ? region(qi) : 0;
-  unsigned bidx[8];      // 32 x 8-bit table indices
-  unsigned kvalid = 0u;  // key exists (index < 49)
-  unsigned kmask = 0u;   // -100 applies
+  const int qbase = iy * (2 * WS - 1) + ix + (WS - 1) * (2 * WS - 1) + (WS - 1);
+  unsigned cj[8];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int slot = kt * 16 + r;
-      const int j = kt * 32 + crow_(r, hf);
-      const int jc = min(j, NTOK - 1);
-      const int jy = jc / WS, jx = jc % WS;
-      const unsigned idx = (unsigned)((iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1));
-      if ((slot & 3) == 0) bidx[slot >> 2] = 0u;
-      bidx[slot >> 2] |= idx << (8 * (slot & 3));
-      if (j < NTOK) kvalid |= 1u << slot;
-      if (p.shift > 0 && region(jc) != rid) kmask |= 1u << slot;
-    }
+  for (int i = 0; i < 8; ++i) cj[i] = hf ? p.cj[1][i] : p.cj[0][i];
+  const unsigned kvalid = hf ? p.kvalid[1] : p.kvalid[0];
+  unsigned kmask = 0u;
+  if (p.shift > 0) {
+    const unsigned rowhi = hf ? p.rowhi[1] : p.rowhi[0], colhi = hf ? p.colhi[1] : p.colhi[0];
+    if (wy == p.nWy - 1) kmask |= (iy >= WS - p.shift) ? ~rowhi : rowhi;
+    if (wx == p.nWx - 1) kmask |= (ix >= WS - p.shift) ? ~colhi : colhi;
+  }
 
   f32x16 oacc[NTL];
 #pragma unroll
@@ -256,14 +258,6 @@ __global__ void __launch_bounds__(256, 1) swin_attn_fused_kernel(const SwinArgs 
 
   int stage = 0;  // ring stage (0 / 1) being consumed
   for (int h = 0; h < NH; ++h) {
-    // biases of the head: q / k rows in accumulator order (16 per lane), v per lane (its column d = l31)
-    f32x4 bq[4], bk[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bq[g] = *reinterpret_cast<const f32x4*>(sQB + h * 32 + 8 * g + 4 * hf);
-      bk[g] = *reinterpret_cast<const f32x4*>(sQB + C + h * 32 + 8 * g + 4 * hf);
-    }
-    const float bv = sQB[2 * C + h * 32 + l31];
     f32x16 acc;  // the projection being accumulated (q, then k, then v)
     HL qB[2];    // q^T of the head as B fragments
     h16x8 oh[2], ol[2];  // O^T of the head as B fragments (built after the attention core)
@@ -276,11 +270,19 @@ __global__ void __launch_bounds__(256, 1) swin_attn_fused_kernel(const SwinArgs 
       if constexpr (sg < SLOTS) dma((stage ^ 1) * STAGE, sg);  // the next stage's pieces, one DMA per step
       if constexpr (s < 3 * KS) {
         constexpr int ph = s / KS, ks = s % KS;  // 0 q, 1 k, 2 v
-        if constexpr (ks == 0) {
+        if constexpr (ks == 0) {  // the accumulator starts from the bias: q / k rows in accumulator order, v per lane (d = l31)
+          if constexpr (ph < 2) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(sQB + ph * C + h * 32 + 8 * g + 4 * hf);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[4 * g + c] = ph == 0 ? bq[g][c] : (ph == 1 ? bk[g][c] : bv);
+              for (int c = 0; c < 4; ++c) acc[4 * g + c] = bb[c];
+            }
+          } else {
+            const float bv = sQB[2 * C + h * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = bv;
+          }
         }
         if constexpr (ph < 2) mma3(acc, fh, fl, xh[ks], xl[ks], single);  // W x^T: lane = token
         else mma3(acc, xh[ks], xl[ks], fh, fl, single);                   // x W^T: lane = d
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(256, 1) swin_attn_fused_kernel(const SwinArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int slot = kt * 16 + r;
-            float a = sc[kt][r] + sB[h * K_::SB_PITCH + ((bidx[slot >> 2] >> (8 * (slot & 3))) & 0xffu)];
+            float a = sc[kt][r] + sB[h * K_::SB_PITCH + qbase - (int)((cj[slot >> 2] >> (8 * (slot & 3))) & 0xffu)];
             if (kmask & (1u << slot)) a += -100.0f;
             a = (kvalid & (1u << slot)) ? a : -3.0e38f;
             sc[kt][r] = a;
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(256) swin_attn_pack_kernel(const float* __rest
 
 bool swin_shape_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
 long long swin_real_units(int C) { return (long long)(C / 32) * 2 * (C / 4) * 64; }
-long long swin_units(int C) { return swin_real_units(C) + (long long)((C == 96) ? 24 : 16) * 2 * 64; }
+long long swin_units(int C) { return swin_real_units(C) + (long long)((C <= SWIN_OCC2_MAXC) ? 8 : 16) * 2 * 64; }
 
 template <int C>
 void swin_launch(const SwinArgs& a, hipStream_t s) {
@@ -479,6 +481,19 @@ extern "C" int tce_swin_attn_fused_f32(const float* x, int64_t ldx, const void* 
   a.g1 = gamma1; a.be1 = beta1; a.ldx = ldx; a.ldo = ldo; a.T = T; a.H = H; a.W = W;
   a.nWy = (H + WS - 1) / WS; a.nWx = (W + WS - 1) / WS; a.shift = shift;
   a.nwin = (long long)T * a.nWy * a.nWx; a.eps = eps; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  for (int hf = 0; hf < 2; ++hf) {
+    a.kvalid[hf] = a.rowhi[hf] = a.colhi[hf] = 0u;
+    for (int i = 0; i < 8; ++i) a.cj[hf][i] = 0u;
+    for (int slot = 0; slot < 32; ++slot) {
+      const int kt = slot >> 4, r = slot & 15;
+      const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, jc = j < NTOK ? j : NTOK - 1;
+      const int jy = jc / WS, jx = jc % WS;
+      a.cj[hf][slot >> 2] |= (unsigned)(jy * (2 * WS - 1) + jx) << (8 * (slot & 3));
+      if (j < NTOK) a.kvalid[hf] |= 1u << slot;
+      if (jy >= WS - shift) a.rowhi[hf] |= 1u << slot;
+      if (jx >= WS - shift) a.colhi[hf] |= 1u << slot;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   if (C == 256) swin_launch<256>(a, s);
   else if (C == 192) swin_launch<192>(a, s);

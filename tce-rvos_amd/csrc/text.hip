@@ -55,19 +55,28 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
 
 // Short-sequence self-attention with head_dim 64 (12 heads x 64 for RoBERTa-base).  One workgroup per head; K and V
 // of the whole sentence (L <= 128 tokens) live in LDS; lane = query row.
+// splits > 1 / bias: qkv is given as `splits` partial planes [L, 3E] (split-K partial sums, plane stride L*3E) + a bias [3E]:
+// the reduction of the projection rides in this kernel's loads (no reduce launch between projection and attention).
 template <int HDIM, int LMAX>
 __global__ void __launch_bounds__(128) mha_small_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
-                                                        int nheads, float scale) {
+                                                        int nheads, float scale, int splits, const float* __restrict__ bias) {
   __shared__ __attribute__((aligned(16))) float sK[LMAX * HDIM];
   __shared__ __attribute__((aligned(16))) float sV[LMAX * HDIM];
   const int h = blockIdx.x;
   const int E = nheads * HDIM;
   const int tid = threadIdx.x;
+  const long long plane = (long long)L * 3 * E;
+  auto ld4 = [&](const float* p, int col) {  // sum of the partial planes (+ bias) at p
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(p + s * plane);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+    return v;
+  };
   for (int i = tid; i < L * (HDIM / 4); i += 128) {
     const int j = i / (HDIM / 4), d4 = i % (HDIM / 4);
     const float* p = qkv + (long long)j * 3 * E + h * HDIM + d4 * 4;
-    *reinterpret_cast<f32x4*>(&sK[j * HDIM + d4 * 4]) = *reinterpret_cast<const f32x4*>(p + E);
-    *reinterpret_cast<f32x4*>(&sV[j * HDIM + d4 * 4]) = *reinterpret_cast<const f32x4*>(p + 2 * E);
+    *reinterpret_cast<f32x4*>(&sK[j * HDIM + d4 * 4]) = ld4(p + E, E + h * HDIM + d4 * 4);
+    *reinterpret_cast<f32x4*>(&sV[j * HDIM + d4 * 4]) = ld4(p + 2 * E, 2 * E + h * HDIM + d4 * 4);
   }
   __syncthreads();
   // four lanes per query (a quarter of the head dim each): the score is a 16-term partial dot + two shuffles, the output
@@ -80,7 +89,7 @@ __global__ void __launch_bounds__(128) mha_small_kernel(const float* __restrict_
     const float* p = qkv + (long long)ic * 3 * E + h * HDIM + part * QD;
 #pragma unroll
     for (int d4 = 0; d4 < QD / 4; ++d4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d4 * 4);
+      const f32x4 v = ld4(p + d4 * 4, h * HDIM + part * QD + d4 * 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) q[d4 * 4 + c] = v[c] * scale;
     }
@@ -148,8 +157,20 @@ extern "C" int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int3
   TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_f32: sequence length %d outside 1..128", L);
   TCE_CHECK_ARG(tce_aligned16(qkv) && tce_aligned16(out), "tce_mha_small64_f32: pointers must be 16-byte aligned");
   hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(128), 0, (hipStream_t)stream, qkv, out, L,
-                     nheads, scale);
+                     nheads, scale, 1, (const float*)nullptr);
   TCE_CHECK_LAUNCH("tce_mha_small64_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_mha_small64_splits_f32(const float* qkv_planes, int32_t splits, const float* bias, float* out, int32_t L,
+                                          int32_t nheads, float scale, tceStream stream) {
+  TCE_CHECK_ARG(qkv_planes && out && nheads > 0 && splits >= 1 && splits <= 64, "tce_mha_small64_splits_f32: bad arguments");
+  TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_splits_f32: sequence length %d outside 1..128", L);
+  TCE_CHECK_ARG(tce_aligned16(qkv_planes) && tce_aligned16(out) && (!bias || tce_aligned16(bias)),
+                "tce_mha_small64_splits_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(128), 0, (hipStream_t)stream, qkv_planes, out,
+                     L, nheads, scale, splits, bias);
+  TCE_CHECK_LAUNCH("tce_mha_small64_splits_f32");
   return TCE_OK;
 }
 

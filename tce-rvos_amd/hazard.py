@@ -337,6 +337,19 @@ MODELS = {
          dense(_p(a[3]), a[10] * F)],
         [strided(_p(a[4]), a[10] * F, (a[6] * a[7] * a[8], a[5] * F))]),
     "tce_fewrow_linear_f32": lambda a: _fewrow(_st(a[0])),
+    # x, ldx, xsplits, bias_x, act_x, W, ldw, ws, M, N, K
+    "tce_thin_partials_f32": lambda a: (
+        [(strided(_p(a[0]), a[10] * F, (a[8], a[1] * F)) if a[2] == 0 else dense(_p(a[0]), a[2] * a[8] * a[10] * F)),
+         dense(_p(a[3]), a[10] * F), strided(_p(a[5]), a[10] * F, (a[9], a[6] * F))],
+        [dense(_p(a[7]), (a[10] // 256) * a[8] * a[9] * F)]),
+    # ws, splits, M, N, bias, act, res, ldres, res_mode, C, ldc, gamma, beta, eps
+    "tce_splitk_reduce_f32": lambda a: (
+        [dense(_p(a[0]), a[1] * a[2] * a[3] * F), dense(_p(a[4]), a[3] * F), dense(_p(a[11]), a[3] * F), dense(_p(a[12]), a[3] * F)] +
+        ([strided(_p(a[6]), a[3] * F, (a[2], a[7] * F))] if a[8] else []),
+        [strided(_p(a[9]), a[3] * F, (a[2], a[10] * F))]),
+    # planes, splits, bias, out, L, nheads
+    "tce_mha_small64_splits_f32": lambda a: ([dense(_p(a[0]), a[1] * a[4] * 3 * a[5] * 64 * F), dense(_p(a[2]), 3 * a[5] * 64 * F)],
+                                             [dense(_p(a[3]), a[4] * a[5] * 64 * F)]),
     "tce_swin_attn_pack_f32": lambda a: ([dense(_p(a[0]), 3 * a[3] * a[3] * F), dense(_p(a[1]), a[3] * a[3] * F)],
                                          [dense(_p(a[2]), _lib.lib_raw().tce_swin_attn_packed_bytes(a[3]))]),
     # x, ldx, packed, qkv_bias, proj_bias, table, g1, be1, eps, out, ldo, T, H, W, C, shift
@@ -349,7 +362,7 @@ MODELS = {
 # Entry points that launch nothing (queries, process switches, graph helpers, tuning aids): passed through.
 NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode", "tce_set_gemm_mode_thread",
                 "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes",
-                "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_swin_attn_packed_bytes", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
+                "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_swin_attn_packed_bytes", "tce_thin_linear_splits", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
                 "tce_graph_destroy"} | set(_lib.DEBUG_SIGNATURES)
 
 

@@ -792,6 +792,37 @@ def splitk_for(M, N, K):
     return s
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Thin linear layers as weight streams (csrc/thin.hip): a few dozen rows against a wide / deep weight (RoBERTa at 32 tokens)
+# ---------------------------------------------------------------------------------------------------------------
+THIN_ENABLED = os.environ.get("TCE_THIN", "1") != "0"
+
+
+def thin_splits(M, N, K):
+    """Partial planes tce_thin_partials_f32 leaves for this shape (K / 256), or 0 when the shape / arithmetic is not its."""
+    if not THIN_ENABLED or get_gemm_mode() == "f32":
+        return 0
+    s = lib().tce_thin_linear_splits(M, N, K)
+    return s if s > 0 else 0
+
+
+def thin_partials(x, w, ws, M, N, K, ldx=None, xsplits=0, bias_x=None, act_x=ACT_NONE):
+    """ws[s][M][N] (s < K/256) = partial sums of x W^T.  xsplits > 0: x is itself [xsplits][M][K] partial planes of the previous
+    layer, finished on load as act_x(sum + bias_x)."""
+    check(lib().tce_thin_partials_f32(x.data_ptr(), K if ldx is None else ldx, xsplits, bias_x.data_ptr() if bias_x is not None else None,
+                                      act_x, w.data_ptr(), w.stride(0), ws.data_ptr(), M, N, K, _stream()), "tce_thin_partials_f32")
+    return ws
+
+
+def splitk_reduce(ws, splits, M, N, out, bias=None, act=ACT_NONE, res=None, ldres=0, res_mode=RES_NONE, ln=None, eps=1e-5, ldc=None):
+    """out = LN?( epi( sum of the partial planes + bias ) )"""
+    check(lib().tce_splitk_reduce_f32(ws.data_ptr(), splits, M, N, bias.data_ptr() if bias is not None else None, act,
+                                      res.data_ptr() if res_mode != RES_NONE else None, ldres, res_mode, out.data_ptr(),
+                                      N if ldc is None else ldc, ln[0].data_ptr() if ln is not None else None,
+                                      ln[1].data_ptr() if ln is not None else None, eps, _stream()), "tce_splitk_reduce_f32")
+    return out
+
+
 def select_masks(pred_logits, pred_masks, out_hw, threshold=0.5):
     """Caller harness H (inference_ytvos.py:238-250) on the GPU: pred_logits [T,Q,K], pred_masks [T,Q,h,w]
     -> (uint8 masks [T,H0,W0], best-query index tensor [1] int32)."""

@@ -54,6 +54,27 @@ class TextPlan:
         # M = L (32 tokens) against 768..3072-deep weights: split K so that ~200 workgroups stream each weight matrix
         # instead of N/64 (ops.splitk_for); the partial sums meet in `ws`
         sk_qkv, sk_out, sk_f1, sk_f2 = (ops.splitk_for(L, n, k) for n, k in ((3 * C, C), (C, C), (self.ff, C), (C, self.ff)))
+        # Weight-stream form (csrc/thin.hip): every dense layer is ONE launch that requests its whole weight matrix at once and
+        # leaves K/256 partial planes; the planes meet in the next consumer (attention reads the qkv planes, fc2 reads fc1's
+        # planes + bias + GELU) or in one reduce(+LayerNorm) launch: 7 launches per layer instead of 9, each a single round
+        # trip (13 us -> a few us per projection, profiles/r04_thin_linear.txt)
+        t_qkv, t_out, t_f1, t_f2 = (ops.thin_splits(L, n, k) for n, k in ((3 * C, C), (C, C), (self.ff, C), (C, self.ff)))
+        if min(t_qkv, t_out, t_f1, t_f2) > 0:
+            ws_a = A(max(t_qkv * L * 3 * C, t_f1 * L * self.ff))   # qkv planes / fc1 planes
+            ws_b = A(max(t_out * L * C, t_f2 * L * C))             # out-proj planes / fc2 planes
+            for wqkv, bqkv, p in self.layers:
+                ops.thin_partials(x, wqkv, ws_a, L, 3 * C, C)
+                check(lib().tce_mha_small64_splits_f32(ws_a.data_ptr(), t_qkv, bqkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s),
+                      "tce_mha_small64_splits_f32")
+                ops.thin_partials(att, sd[p + "attention.output.dense.weight"], ws_b, L, C, C)
+                ops.splitk_reduce(ws_b, t_out, L, C, x, bias=sd[p + "attention.output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
+                                  ln=(sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"]), eps=self.eps)
+                ops.thin_partials(x, sd[p + "intermediate.dense.weight"], ws_a, L, self.ff, C)
+                ops.thin_partials(ws_a, sd[p + "output.dense.weight"], ws_b, L, C, self.ff, xsplits=t_f1,
+                                  bias_x=sd[p + "intermediate.dense.bias"], act_x=ACT_GELU)
+                ops.splitk_reduce(ws_b, t_f2, L, C, x, bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
+                                  ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]), eps=self.eps)
+            return self._pooler(x, A, s)
         ws = A(max(sk_qkv * L * 3 * C, sk_out * L * C, sk_f1 * L * self.ff, sk_f2 * L * C))
         for wqkv, bqkv, p in self.layers:
             gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
@@ -67,6 +88,10 @@ class TextPlan:
             gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
                     bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws, ln_eps=self.eps,
                     ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]))
+        return self._pooler(x, A, s)
+
+    def _pooler(self, x, A, s):
+        sd, C = self.sd, self.C
         pooled = A(C)
         gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])
         check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), C, s), "tce_tanh_f32")

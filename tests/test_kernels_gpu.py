@@ -206,6 +206,46 @@ def test_window_attention(ops, T, H, W, nH, shift):
     close(out2, ref, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 2304, 768), (32, 768, 3072), (7, 768, 768), (100, 3072, 768), (1, 32, 256)])
+def test_thin_linear_weight_stream(ops, M, N, K):
+    """csrc/thin.hip: the partial planes of x W^T, finished by tce_splitk_reduce_f32 (bias / GELU / residual / LayerNorm) or
+    by the next layer's loads (partial planes + bias + GELU as the x operand), against fp64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.3
+    res = torch.randn(M, N, generator=g)
+    splits = ops.thin_splits(M, N, K)
+    assert splits == K // 256
+    ws = torch.empty(splits, M, N, device="cuda")
+    ops.thin_partials(dev(x), dev(w), ws, M, N, K)
+    ref = x.double() @ w.double().T
+    scale = (x.double().abs() @ w.double().abs().T).max().item()
+    assert ((ws.sum(0).cpu().double() - ref).abs().max().item()) < 2e-6 * scale          # fp32-class (3 x fp16 split)
+    out = ops.splitk_reduce(ws, splits, M, N, torch.empty(M, N, device="cuda"), bias=dev(b), act=ops.ACT_GELU)
+    close(out, F.gelu(F.linear(x, w, b)), 1e-4, 1e-4)
+    out = ops.splitk_reduce(ws, splits, M, N, dev(res).clone(), bias=dev(b), res=dev(res), ldres=N, res_mode=ops.RES_ADD)
+    close(out, F.linear(x, w, b) + res, 1e-4, 1e-4)
+    if N <= 1024:
+        ga, be = torch.randn(N, generator=g), torch.randn(N, generator=g)
+        buf = dev(res).clone()   # in place on the residual stream
+        ops.splitk_reduce(ws, splits, M, N, buf, bias=dev(b), res=buf, ldres=N, res_mode=ops.RES_ADD, ln=(dev(ga), dev(be)), eps=1e-5)
+        close(buf, F.layer_norm(F.linear(x, w, b) + res, (N,), ga, be, 1e-5), 2e-4, 2e-4)
+    # the planes as the NEXT layer's x operand: y = GELU(x W^T + b) W2^T with no reduction launch in between
+    if N % 256 == 0:
+        N2 = 64
+        w2 = torch.randn(N2, N, generator=g) / math.sqrt(N)
+        ws2 = torch.empty(N // 256, M, N2, device="cuda")
+        ops.thin_partials(ws, dev(w2), ws2, M, N2, N, xsplits=splits, bias_x=dev(b), act_x=ops.ACT_GELU)
+        close(ws2.sum(0), F.linear(F.gelu(F.linear(x, w, b)), w2), 2e-4, 2e-4)
+    with ops.arith("f16"):
+        ws16 = ops.thin_partials(dev(x), dev(w), torch.empty_like(ws), M, N, K)
+    d16 = (ws16.sum(0).cpu().double() - ref).abs().max().item()
+    assert 0 < d16 < 2e-3 * scale
+    with ops.arith("f32"):
+        assert ops.thin_splits(M, N, K) == 0    # exact-fp32 mode keeps the tiled fp32-MFMA GEMM
+
+
 def _swin_half_ref(x, sd, T, H, W, nH, shift):
     """x + proj(window_attention(norm1(x))) from the oracle's SwinTransformerBlock (pinned to the reference by the e2e
     fixtures): the block with an MLP whose second layer is zero."""
