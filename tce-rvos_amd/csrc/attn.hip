@@ -1094,7 +1094,8 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
     sSrc[n] = src;
     sCR[n] = cr;
   }
-  for (int i = tid; i < table_rows; i += nthr) sB[i] = table[(long long)i * nH + h];
+  // the table is kept pre-multiplied by log2(e): the softmax below runs in base 2 (v_exp_f32 IS 2^x; one multiply per score saved)
+  for (int i = tid; i < table_rows; i += nthr) sB[i] = table[(long long)i * nH + h] * 1.4426950408889634f;
   __syncthreads();
   // K -> [key][32 halfs] hi / lo planes, V -> transposed [d][key] hi / lo planes; rows past N are zero
   for (int i = tid; i < NKP * 8; i += nthr) {
@@ -1130,7 +1131,7 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
   }
   __syncthreads();
   const bool masked = (g.sd | g.sh | g.sw) != 0;
-  const float scale = 0.17677669529663687f;
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 * log2(e): base-2 softmax
   const int koff = ((g.fd - 1) * (2 * g.fh - 1) + (g.fh - 1)) * (2 * g.fw - 1) + (g.fw - 1);
   const int nkt = NKP / 32, nqt = (N + 31) / 32;
   for (int qt = wave; qt < nqt; qt += NW) {
@@ -1138,7 +1139,9 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
     const int qc = min(qi, N - 1);
     const int srow = sSrc[qc];
     const int crq = sCR[qc];
-    const int ci = (crq & 0xffff) + koff, rid = crq >> 16;
+    // query word - key word = (table index) | (region difference << 16): ONE subtraction per score gives both the relative-
+    // position index (low 16 bits; never borrows: code_q + koff >= code_k) and "the -100 mask applies" (high bits != 0)
+    const int cq = crq + koff;
     ah16x8 qh[2], ql[2];
     {
       const float* p = srow >= 0 ? qkv + (long long)srow * C3 + h * HD : qkv_bias + h * HD;
@@ -1175,24 +1178,28 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
         st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], st, 0, 0, 0);
       }
       float tmax = -3.0e38f;
+      const bool ragged = k0 + 32 > N;  // only the last key tile can hold keys that do not exist (wave-uniform)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = k0 + crow(r, lhi);
-        const int cr = sCR[j];
-        float a = st[r] + sB[ci - (cr & 0xffff)];
-        if (masked && (cr >> 16) != rid) a += -100.0f;
-        if (j >= N) a = -3.0e38f;
+        const int df = cq - sCR[j];
+        float a = st[r] + sB[df & 0xffff];
+        if (masked) a += (df >> 16) != 0 ? -144.26950408889634f : 0.f;  // -100 * log2(e)
+        if (ragged && j >= N) a = -3.0e38f;
         st[r] = a;
         tmax = fmaxf(tmax, a);
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(m, tmax);
-      const float corr = __expf(m - mnew);
-      l *= corr;
+      if (__builtin_amdgcn_ballot_w64(mnew > m) != 0) {  // the running maximum of some query moved: rescale (else corr = 1 for all)
+        const float corr = __builtin_amdgcn_exp2f(m - mnew);
+        l *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        o[r] *= corr;
-        const float pj = (st[r] > -1.0e38f) ? __expf(st[r] - mnew) : 0.f;
+        float pj = __builtin_amdgcn_exp2f(st[r] - mnew);  // exp2(-3e38 - m) = 0 for the keys that do not exist
         st[r] = pj;
         l += pj;
       }

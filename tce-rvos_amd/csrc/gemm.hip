@@ -370,6 +370,51 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // The same reduction with the LayerNorm that follows it in every post-norm block (RoBERTa's attention.output / output
 // sub-layers, the decoder's FFN): one wavefront per output row (N <= 1024) sums the splits, adds bias + residual and
 // normalises the row -- the LayerNorm launch behind a split-K GEMM disappears (24 per clip in the text encoder alone).
+// Few-row form of the reduction + LayerNorm (M <= 256 rows: RoBERTa at 32 tokens, the decoder at 25): ONE WORKGROUP per row,
+// thread t owns float4 t of the row (N <= 1024), so every partial plane's load of the row is in flight at once -- one memory
+// round trip instead of the wave-per-row kernel's serial walk over the planes (8.6 us for 32 x 768 x 16 planes on 8
+// workgroups).  Same arithmetic: planes summed in split order, + bias + residual, two-pass mean / variance over the row.
+__global__ void __launch_bounds__(256) splitk_reduce_ln_row_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                   const float* res, float* C, const int M, const int N,
+                                                                   const int splits, const int ldc, const int ldres,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float eps) {
+  __shared__ float sPart[2][4];
+  const int m = blockIdx.x, t = threadIdx.x, n4 = N >> 2;
+  const long long plane = (long long)M * N;
+  const bool on = t < n4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    const float* p = ws + (long long)m * N + 4 * t;
+    a = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(p + (long long)s * plane);
+    if (bias) a += *reinterpret_cast<const f32x4*>(bias + 4 * t);
+    if (res) a += *reinterpret_cast<const f32x4*>(res + (long long)m * ldres + 4 * t);
+  }
+  float sum = wave_sum(on ? (a[0] + a[1]) + (a[2] + a[3]) : 0.f);
+  if ((t & 63) == 0) sPart[0][t >> 6] = sum;
+  __syncthreads();
+  const float mean = ((sPart[0][0] + sPart[0][1]) + (sPart[0][2] + sPart[0][3])) / (float)N;
+  float sq = 0.f;
+  if (on)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = a[c] - mean;
+      sq = fmaf(d, d, sq);
+    }
+  sq = wave_sum(sq);
+  if ((t & 63) == 0) sPart[1][t >> 6] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf(((sPart[1][0] + sPart[1][1]) + (sPart[1][2] + sPart[1][3])) / (float)N + eps);
+  if (on) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * t), b = *reinterpret_cast<const f32x4*>(beta + 4 * t);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (a[c] - mean) * rstd * g[c] + b[c];
+    *reinterpret_cast<f32x4*>(C + (long long)m * ldc + 4 * t) = o;
+  }
+}
+
 // res may alias C (every caller runs it in place on the residual stream): neither is __restrict__, and a row's residual
 // is fully read (it feeds the mean) before the row's first store -- one wavefront owns the row.
 __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
@@ -454,8 +499,12 @@ extern "C" int tce_splitk_reduce_f32(const float* ws, int32_t splits, int32_t M,
     TCE_CHECK_ARG(beta && act == 0 && res_mode != 2 && N <= 1024 && ldc % 4 == 0 && (res_mode == 0 || ldres % 4 == 0) &&
                       tce_aligned16(C) && tce_aligned16(gamma) && tce_aligned16(beta) && (res_mode == 0 || tce_aligned16(res)),
                   "tce_splitk_reduce_f32: LayerNorm form: no activation, additive residual, N <= 1024, 16-byte aligned rows");
-    hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, bias,
-                       res_mode == 1 ? res : nullptr, C, M, N, splits, ldc, ldres, gamma, beta, eps);
+    if (M <= 256)
+      hipLaunchKernelGGL(splitk_reduce_ln_row_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ws, bias,
+                         res_mode == 1 ? res : nullptr, C, M, N, splits, ldc, ldres, gamma, beta, eps);
+    else
+      hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(tce_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, bias,
+                         res_mode == 1 ? res : nullptr, C, M, N, splits, ldc, ldres, gamma, beta, eps);
   } else {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tce_cdiv((long long)M * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, ws, bias,
                        res, C, M, N, splits, ldc, ldres, act, res_mode);
@@ -499,7 +548,10 @@ static int splitk_impl(const tceGemmArgs* args, int32_t splits, float* workspace
   const int st = tce_gemm_f32(&g, stream);
   if (st != TCE_OK) return st;
   const long long total = (long long)a.M * (a.N / 4);
-  if (gamma)
+  if (gamma && a.M <= 256)
+    hipLaunchKernelGGL(splitk_reduce_ln_row_kernel, dim3(a.M), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
+                       a.res_mode == 1 ? a.res : nullptr, a.C, a.M, a.N, splits, a.ldc, a.ldres, gamma, beta, eps);
+  else if (gamma)
     hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(tce_cdiv(a.M, 4)), dim3(256), 0, (hipStream_t)stream, workspace, a.bias,
                        a.res_mode == 1 ? a.res : nullptr, a.C, a.M, a.N, splits, a.ldc, a.ldres, gamma, beta, eps);
   else

@@ -6,15 +6,13 @@
 // round trips); this kernel takes one:
 //
 //   grid (N/32, ceil(M/32), K/256); a workgroup = 32 output columns x 32 rows x 256 of K; each of its 4 waves loads ITS 64
-//   of K of the W slab (32 rows x 256 B per wave, sixteen 16-byte loads per lane, all in flight at once) and of x straight
-//   into registers in MFMA fragment order, splits both to fp16 hi/lo on the fly (W is static but streamed once: a
-//   pre-split copy would double its bytes), multiplies (x as A, W as B: the accumulator has the output column on the lane),
+//   of K of the W slab and of x in full 128-byte lines (8 lanes per row, sixteen 16-byte loads per lane, all in flight at
+//   once), turns them into MFMA fragment order through a per-wave LDS tile, splits both to fp16 hi/lo on the fly (W is static
+//   but streamed once: a pre-split copy would double its bytes), multiplies (x as A, W as B: output column on the lane),
 //   the four waves' tiles are summed through LDS and the sums go to a partial plane ws[kz][M][N] in full 128-byte rows.
 //   The partial planes (K/256 of them) meet in the reduction kernels of gemm.hip (bias, activation, residual, LayerNorm)
 //   or in the NEXT consumer's load: PRO = the x operand is itself given as partial planes + bias (+ GELU) of the previous
 //   layer (fc1 -> fc2 needs no reduction launch); tce_mha_small64_splits_f32 reads q, k, v the same way.
-// Contraction order inside a 32-wide K pair: fragment slot (hf, j) of step 0 <-> k = 16 hf + j, of step 1 <-> k = 16 hf + 8 + j
-// (both operands alike), so a lane reads 64 contiguous bytes of its row per pair.
 #include "common.h"
 #include "frag.h"
 #include "../../include/tce_rvos.h"
@@ -34,55 +32,78 @@ __device__ __forceinline__ int crow_t(int r, int hi) { return (r & 3) + 8 * (r >
 
 template <bool PRO>
 __global__ void __launch_bounds__(256) thin_partials_kernel(const ThinArgs p) {
-  __shared__ __attribute__((aligned(16))) float sRed[4][16][64];
+  // per wave: one staging tile for W and one for x (32 rows x 32 floats, 144-byte pitch: conflict-free for the row-of-8-lanes
+  // writes and the row-per-lane fragment reads alike, see frag.h); the tiles are reused by the wave's two 32-wide K chunks
+  __shared__ __attribute__((aligned(16))) float sT[4][2][32 * WT_PITCH];
+  float (*const sRed)[16][64] = reinterpret_cast<float (*)[16][64]>(&sT[0][0][0]);  // [4][16][64] after the tiles are done (16 of 36 KB)
+  static_assert(sizeof(float) * 4 * 16 * 64 <= sizeof(sT), "reduction buffer aliases the staging tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hf = lane >> 5;
+  const int cr = lane >> 3, cp = (lane & 7) * 4;  // coalesced side: row 8i + cr of the tile, 16-byte piece lane & 7
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, kz = blockIdx.z;
-  const int k0 = kz * 256 + wave * 64 + 16 * hf;  // this lane's first k of pair 0 (pair 1: + 32)
-  const int m = min(m0 + l31, p.M - 1);
+  const int kb = kz * 256 + wave * 64;            // this wave's 64 of K: chunks kb .. kb+31 and kb+32 .. kb+63
+  // every global load of the wave is issued before anything is consumed: ONE memory round trip (full 128-byte lines)
   f32x4 wv[2][4], xv[2][4];
-  const float* wr = p.W + (long long)(n0 + l31) * p.ldw + k0;
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wv[pr][i] = *reinterpret_cast<const f32x4*>(wr + 32 * pr + 4 * i);
-  if (!PRO) {
-    const float* xr = p.x + (long long)m * p.ldx + k0;
+    for (int i = 0; i < 4; ++i)
+      wv[c][i] = *reinterpret_cast<const f32x4*>(p.W + (long long)(n0 + 8 * i + cr) * p.ldw + kb + 32 * c + cp);
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xv[pr][i] = *reinterpret_cast<const f32x4*>(xr + 32 * pr + 4 * i);
-  } else {
-    const long long plane = (long long)p.M * p.K;
-    const float* xr = p.x + (long long)m * p.K + k0;
+    for (int i = 0; i < 4; ++i) {
+      const int m = min(m0 + 8 * i + cr, p.M - 1);
+      if (!PRO) {
+        xv[c][i] = *reinterpret_cast<const f32x4*>(p.x + (long long)m * p.ldx + kb + 32 * c + cp);
+      } else {
+        const float* xr = p.x + (long long)m * p.K + kb + 32 * c + cp;
+        const long long plane = (long long)p.M * p.K;
+        f32x4 a = *reinterpret_cast<const f32x4*>(xr);
+        for (int s = 1; s < p.xsplits; ++s) a += *reinterpret_cast<const f32x4*>(xr + s * plane);
+        xv[c][i] = a;
+      }
+    }
+  if (PRO) {
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
+    for (int c = 0; c < 2; ++c) {
+      f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias_x) bb = *reinterpret_cast<const f32x4*>(p.bias_x + kb + 32 * c + cp);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(xr + 32 * pr + 4 * i);
-        for (int s = 1; s < p.xsplits; ++s) a += *reinterpret_cast<const f32x4*>(xr + s * plane + 32 * pr + 4 * i);
-        if (p.bias_x) a += *reinterpret_cast<const f32x4*>(p.bias_x + k0 + 32 * pr + 4 * i);
+        f32x4 a = xv[c][i] + bb;
         if (p.act_x == 1) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = fmaxf(a[c], 0.f);
+          for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
         } else if (p.act_x == 2) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = 0.5f * a[c] * (1.f + erff(a[c] * 0.70710678118654752440f));
+          for (int e = 0; e < 4; ++e) a[e] = 0.5f * a[e] * (1.f + erff(a[e] * 0.70710678118654752440f));
         }
-        xv[pr][i] = a;
+        xv[c][i] = a;
       }
+    }
   }
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float* const tw = &sT[wave][0][0];
+  float* const tx = &sT[wave][1][0];
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr)
+  for (int c = 0; c < 2; ++c) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const float xf[8] = {xv[pr][2 * st][0], xv[pr][2 * st][1], xv[pr][2 * st][2], xv[pr][2 * st][3],
-                           xv[pr][2 * st + 1][0], xv[pr][2 * st + 1][1], xv[pr][2 * st + 1][2], xv[pr][2 * st + 1][3]};
-      const float wf[8] = {wv[pr][2 * st][0], wv[pr][2 * st][1], wv[pr][2 * st][2], wv[pr][2 * st][3],
-                           wv[pr][2 * st + 1][0], wv[pr][2 * st + 1][1], wv[pr][2 * st + 1][2], wv[pr][2 * st + 1][3]};
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(tw + (8 * i + cr) * WT_PITCH + cp) = wv[c][i];
+      *reinterpret_cast<f32x4*>(tx + (8 * i + cr) * WT_PITCH + cp) = xv[c][i];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // fragment of k-step st: row l31, floats 16 st + 8 hf + 0..7 of the chunk
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(tx + l31 * WT_PITCH + 16 * st + 8 * hf);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(tx + l31 * WT_PITCH + 16 * st + 8 * hf + 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(tw + l31 * WT_PITCH + 16 * st + 8 * hf);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(tw + l31 * WT_PITCH + 16 * st + 8 * hf + 4);
+      const float xf[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      const float wf[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
       const HL a = split8(xf, p.single), b = split8(wf, p.single);
       if (!p.single) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
@@ -90,7 +111,10 @@ __global__ void __launch_bounds__(256) thin_partials_kernel(const ThinArgs p) {
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_wave_barrier();
+  }
   // acc: lane = output column n0 + l31, register i = row m0 + crow(i, hf).  Sum the four waves' tiles through LDS.
+  __syncthreads();  // every wave is done with its staging tiles (the reduction buffer aliases them)
 #pragma unroll
   for (int i = 0; i < 16; ++i) sRed[wave][i][lane] = acc[i];
   __syncthreads();

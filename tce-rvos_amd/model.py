@@ -617,6 +617,14 @@ class ReferFormer(nn.Module):
                 else:
                     out = self._replay(key, ent, (frames, ids))
         ops.range_snapshot_async(frames.device)
+        return self._tag_diagnostics(out)
+
+    @staticmethod
+    def _tag_diagnostics(out):
+        """A diagnostic launch program (TCE_ABLATE: stages skipped) marks every result it returns as garbage."""
+        from . import pipeline
+        if pipeline.ABLATE:
+            out["ablated"] = sorted(pipeline.ABLATE)
         return out
 
     @staticmethod
@@ -854,15 +862,15 @@ class ReferFormer(nn.Module):
         key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training, int(slot),
                self._stamp, valid_hw)
         if not self._want_graph(key):
-            return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw)
+            return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw))
         ent = self._graphs.get(key)
         if ent is None:
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
             ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res, valid=valid_hw), frames,
                                 slot)
             if ent is None:
-                return self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw)
-        return self._replay(key, ent, (frames, text_hidden, text_pooled))
+                return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw))
+        return self._tag_diagnostics(self._replay(key, ent, (frames, text_hidden, text_pooled)))
 
 
 def _flat_outputs(out):

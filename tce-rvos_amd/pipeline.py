@@ -45,7 +45,7 @@ def _lin(A, x, M, K, w, b, N, **kw):
 #       TCE_LAT1_AT; TCE_FEWROW_SITES (bisect aid: which sites take the few-row kernel)
 #   DIAGNOSTICS that change what forward() returns -- set by tools/ only, announced with a warning at import:
 #       TCE_ABLATE (tools/ablate_times.py): the named stages are SKIPPED, results are garbage (the time that disappears is
-#           the stage's share of the critical path); the output dict carries out["ablated"];
+#           the stage's share of the critical path); model.forward() tags its output dict with out["ablated"];
 #       TCE_TAPS=1 (tools/graph_vs_eager.py): copies of intermediates ride out in out["taps"].
 ABLATE = set(filter(None, os.environ.get("TCE_ABLATE", "").split(",")))
 TAPS = os.environ.get("TCE_TAPS") == "1"
@@ -170,7 +170,10 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     def text_stage():
         nonlocal L, fk, fv, fpk, sent
         with text_fork, model.arith("text"):
-            text_hidden, text_pooled = text_in(tA) if callable(text_in) else text_in
+            if "text" in ABLATE and callable(text_in):  # diagnostic: the RoBERTa layers skipped (garbage features)
+                text_hidden, text_pooled = tA(32, cfg.text_hidden), tA(cfg.text_hidden)
+            else:
+                text_hidden, text_pooled = text_in(tA) if callable(text_in) else text_in
             L = text_hidden.shape[0]
             tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
             text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
@@ -668,8 +671,6 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     out["memory"] = keep(memory.reshape(T, S, D))
     if taps:
         out["taps"] = [{k_: keep(v_) for k_, v_ in taps.items()}]
-    if ABLATE:
-        out["ablated"] = sorted(ABLATE)  # these results are garbage by construction (tools/ablate_times.py)
     ar.release(m0)
     return out
 

@@ -8,7 +8,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 extra = sys.argv[1:]
-cases = ["", "decoder", "ftf_tok", "swin2,swin3", "swin0,swin1", "ffn:encoder.ffn", "enc_msda", "ffn:pixel.ffn"]
+cases = ["", "text", "swin2,swin3", "text,swin2,swin3", "swin0,swin1", "decoder", "ftf_tok", "ffn:encoder.ffn", "enc_msda", "ffn:pixel.ffn"]
 base = None
 for c in cases:
     env = dict(os.environ, TCE_ABLATE=c)
