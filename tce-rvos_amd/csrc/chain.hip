@@ -565,11 +565,14 @@ struct LinArgs {
   int single;
 };
 
+// K = 384 (round 4: Swin-T's third stage, 4600 rows at config 2: norm1 -> qkv, proj + residual, norm2 -> fc1 + GELU): the x
+// fragments take 192 registers -> one workgroup per CU (90 KB of LDS); with the output tiles split over gridDim.z the 36 row
+// blocks become ~290 workgroups of 4-6 tiles each, against the tiled GEMM's 12 short K slices per tile (32 us per launch there).
 // K = 96 (Swin-T stage 0) is compiled for THREE workgroups per CU (168 registers, 43 KB of LDS): at config 2 the stage has
 // 72000 rows = 563 row blocks, one more than two per CU hold (512) -- a second, nearly empty round.  47.7 -> 38.5 us for the
 // norm1 -> qkv launch (profiles/r03_rowlin_occupancy.txt).
 template <int K, bool ROW>
-__global__ void __launch_bounds__(256, ROW ? 1 : (K <= 96 ? 3 : 2)) rowlin_kernel(const LinArgs p) {
+__global__ void __launch_bounds__(256, (ROW || K > 256) ? 1 : (K <= 96 ? 3 : 2)) rowlin_kernel(const LinArgs p) {
   // The ring holds HALF blocks (the first / second K/32 k-steps of a 32-channel tile, hi and lo pieces interleaved,
   // padded to a multiple of 4 pieces so that every wave issues the same number of DMAs): three half-stages, the DMA of
   // half h+2 is issued while half h is multiplied.  3 x 16 KiB + staging tiles = 66 KiB at K = 256: two workgroups
@@ -772,7 +775,7 @@ __global__ void __launch_bounds__(256) rowlin_pack_kernel(const float* __restric
   reinterpret_cast<u32x4*>(out)[u] = o;
 }
 
-inline bool rowlin_shape_ok(int N, int K) { return (K == 96 || K == 128 || K == 192 || K == 256) && N > 0 && N % 32 == 0; }
+inline bool rowlin_shape_ok(int N, int K) { return (K == 96 || K == 128 || K == 192 || K == 256 || K == 384) && N > 0 && N % 32 == 0; }
 inline long long rowlin_units(int N, int K) {
   const int HP = (2 * (K / 32) + 3) / 4 * 4;
   return (long long)(2 * (N / 32) + 2) * HP * 64;
@@ -1366,7 +1369,8 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   const int batch = q.batch > 0 ? q.batch : 1;
   const bool row = q.g_out != nullptr;
   hipStream_t s = (hipStream_t)stream;
-  if (q.K == 256) rowlin_launch<256>(a, batch, row, s);
+  if (q.K == 384) rowlin_launch<384>(a, batch, row, s);  // Swin stage 3 (C = 384): x = 192 registers, one workgroup per CU
+  else if (q.K == 256) rowlin_launch<256>(a, batch, row, s);
   else if (q.K == 192) rowlin_launch<192>(a, batch, row, s);
   else if (q.K == 128) rowlin_launch<128>(a, batch, row, s);
   else rowlin_launch<96>(a, batch, row, s);

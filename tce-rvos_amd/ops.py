@@ -759,6 +759,10 @@ def _rowlin_route(w, M, N, K, ldw, batch):
     if K not in ROWLIN_K or N % 32 or get_gemm_mode() == "f32":
         return None
     rows = M * max(1, batch)
+    if K == 384:  # Swin-T stage 3 (4600 rows at config 2): the tiled GEMM's 12 K slices per tile are latency-bound there
+        if rows < 2048 or M < 2048 or N < 384:
+            return None
+        return _ROUTES.rowlin.get((w.data_ptr(), N, K, ldw, get_gemm_mode()))
     if rows < ROWLIN_MIN_ROWS or M < 2048:
         return None
     if not (K <= 128 and rows >= 32768) and not (K >= 192 and N >= 384 and N != 576):
@@ -937,7 +941,7 @@ def current_routes():
 
 
 ROWLIN_MIN_ROWS = int(os.environ.get("TCE_ROWLIN_MIN_ROWS", 12000))
-ROWLIN_K = (96, 128, 192, 256)
+ROWLIN_K = (96, 128, 192, 256, 384) if os.environ.get("TCE_ROWLIN_K384", "1") != "0" else (96, 128, 192, 256)  # A/B switch
 
 
 def rowlin_pack(w, N=None, K=None, ldw=None):

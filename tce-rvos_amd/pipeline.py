@@ -716,7 +716,8 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
             if pk_attn is None:
                 with model.arith("backbone.attn"):  # x += proj(window attention(qkv(norm1 x))) as three launches
                     qkv = A(ntok, 3 * C)
-                    pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) if (C <= 128 and ntok >= 32768) else None
+                    pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) \
+                        if ((C <= 128 and ntok >= 32768) or (C == 384 and ntok >= 2048)) else None
                     if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
                         ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
                                    ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
@@ -737,10 +738,15 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
                     ops.ffn_fused(x, pk, w[p + "mlp.fc2.bias"], hid, ACT_GELU, M=ntok,
                                   ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
                 else:
-                    ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
                     hdn = A(ntok, hid)
-                    gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
-                            act=ACT_GELU)
+                    pk1 = ops.rowlin_lookup(w[p + "mlp.fc1.weight"], hid, C) if (C == 384 and ntok >= 2048) else None
+                    if pk1 is not None:  # norm2 -> fc1 -> GELU in one token-stationary launch (LayerNorm prologue)
+                        ops.rowlin(x, pk1, hdn, ntok, hid, C, C, hid, bias=w[p + "mlp.fc1.bias"], act=ACT_GELU,
+                                   ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
+                    else:
+                        ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], out=xn)
+                        gemm_ex(xn, w[p + "mlp.fc1.weight"], hdn, ntok, hid, C, C, C, hid, bias=w[p + "mlp.fc1.bias"],
+                                act=ACT_GELU)
                     # last stage: ~1200 rows against K = 3072 -- 228 workgroups walking 96 K slices each; split-K: 61 -> 41 us
                     sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
                         if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1

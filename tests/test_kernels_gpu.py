@@ -804,7 +804,8 @@ def test_split_fp16_range_guard(ops):
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(24100, 256, 256, 1), (4820, 384, 256, 5), (7200, 288, 96, 1), (1000, 576, 192, 2),
-                                         (333, 128, 128, 1), (129, 32, 96, 1)])
+                                         (333, 128, 128, 1), (129, 32, 96, 1),
+                                         (4600, 1152, 384, 1), (4600, 384, 384, 1), (920, 1536, 384, 5), (200, 256, 384, 1)])
 @pytest.mark.parametrize("variant", ["plain", "a2_relu", "res_mul", "gelu_res", "ln_in", "ln_out"])
 def test_rowlin(ops, M, N, K, batch, variant):
     """Token-stationary linear kernel (tce_rowlin_f32) against torch fp32 of the op sequence it replaces: addend with a
