@@ -786,7 +786,13 @@ void rowlin_launch(const LinArgs& a, int batch, bool row, hipStream_t s) {
   // aim at >= ~3 workgroups per CU-pair slot: split the output tiles when the row blocks alone leave the chip idle
   const int rb = tce_cdiv(a.M, 128) * batch, ntiles = a.N / 32;
   int nz = 1;
-  if (!row) {
+  if (!row && K > 256) {
+    // one workgroup per CU (x alone takes 192 registers): exactly ONE round of <= 256 workgroups, at least two tiles each
+    // (36 row blocks x 8 splits = 288 workgroups ran a second, nearly empty round: slower than the tiled GEMM)
+    nz = 256 / (rb > 0 ? rb : 1);
+    if (nz > ntiles / 2) nz = ntiles / 2;
+    if (nz < 1) nz = 1;
+  } else if (!row) {
     while (nz < ntiles && rb * nz < 160 && ntiles / (nz * 2) >= 2) nz *= 2;  // only launches with few row blocks
   }
   const dim3 grid(tce_cdiv(a.M, 128), batch, nz), block(256);

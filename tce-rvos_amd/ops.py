@@ -759,8 +759,9 @@ def _rowlin_route(w, M, N, K, ldw, batch):
     if K not in ROWLIN_K or N % 32 or get_gemm_mode() == "f32":
         return None
     rows = M * max(1, batch)
-    if K == 384:  # Swin-T stage 3 (4600 rows at config 2): the tiled GEMM's 12 K slices per tile are latency-bound there
-        if rows < 2048 or M < 2048 or N < 384:
+    if K == 384:  # Swin-T stage 3 (4600 rows at config 2, 7680 at config 3): the tiled GEMM's 12 K slices per tile are latency-
+        # bound there; from ~12000 rows on the tiled kernel wins again (18000 rows: 94 vs 104 us, tools/rowlin384_bench.py)
+        if rows < 2048 or M < 2048 or N < 384 or rows > ROWLIN384_MAX_ROWS:
             return None
         return _ROUTES.rowlin.get((w.data_ptr(), N, K, ldw, get_gemm_mode()))
     if rows < ROWLIN_MIN_ROWS or M < 2048:
@@ -941,6 +942,7 @@ def current_routes():
 
 
 ROWLIN_MIN_ROWS = int(os.environ.get("TCE_ROWLIN_MIN_ROWS", 12000))
+ROWLIN384_MAX_ROWS = int(os.environ.get("TCE_ROWLIN384_MAX_ROWS", 12000))
 ROWLIN_K = (96, 128, 192, 256, 384) if os.environ.get("TCE_ROWLIN_K384", "1") != "0" else (96, 128, 192, 256)  # A/B switch
 
 

@@ -717,7 +717,7 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
                 with model.arith("backbone.attn"):  # x += proj(window attention(qkv(norm1 x))) as three launches
                     qkv = A(ntok, 3 * C)
                     pk = ops.rowlin_lookup(w[p + "attn.qkv.weight"], 3 * C, C) \
-                        if ((C <= 128 and ntok >= 32768) or (C == 384 and ntok >= 2048)) else None
+                        if ((C <= 128 and ntok >= 32768) or (C == 384 and 2048 <= ntok <= ops.ROWLIN384_MAX_ROWS)) else None
                     if pk is not None:  # norm1 -> qkv in one token-stationary launch (LayerNorm prologue)
                         ops.rowlin(x, pk, qkv, ntok, 3 * C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"],
                                    ln_in=(w[p + "norm1.weight"], w[p + "norm1.bias"]))
@@ -739,7 +739,7 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
                                   ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
                 else:
                     hdn = A(ntok, hid)
-                    pk1 = ops.rowlin_lookup(w[p + "mlp.fc1.weight"], hid, C) if (C == 384 and ntok >= 2048) else None
+                    pk1 = ops.rowlin_lookup(w[p + "mlp.fc1.weight"], hid, C) if (C == 384 and 2048 <= ntok <= ops.ROWLIN384_MAX_ROWS) else None
                     if pk1 is not None:  # norm2 -> fc1 -> GELU in one token-stationary launch (LayerNorm prologue)
                         ops.rowlin(x, pk1, hdn, ntok, hid, C, C, hid, bias=w[p + "mlp.fc1.bias"], act=ACT_GELU,
                                    ln_in=(w[p + "norm2.weight"], w[p + "norm2.bias"]))
