@@ -378,6 +378,10 @@ typedef struct {
 int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
                           float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream);
 int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream);
+/* tce_xattn_prepare_f32 + tce_ffn_pack_batched_f32 in ONE launch: k, v [batch][L,256] -> `batch` contiguous weight streams of
+ * tce_ffn_packed_bytes(256, 8*group) bytes each, bit-identical to the two-launch form. */
+int tce_xattn_pack_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, void* packed, int32_t L, int32_t group,
+                       int32_t batch, tceStream stream);
 
 /* Swin attention half-block as ONE launch (csrc/swinattn.hip):
  *     out = x + proj( window_attention( LayerNorm_norm1(x) ) )                                   C in {96, 128, 192, 256}

@@ -108,6 +108,7 @@ SIGNATURES = {
     "tce_xattn_prepare_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_ffn_pack_batched_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_xattn_fused_f32": (i32, [C.POINTER(XattnArgs), c_f]),
+    "tce_xattn_pack_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_rowlin_packed_bytes": (i64, [i32, i32]),
     "tce_rowlin_pack_f32": (i32, [c_f, i64, c_f, i32, i32, c_f]),
     "tce_rowlin_f32": (i32, [C.POINTER(RowLinArgs), c_f]),

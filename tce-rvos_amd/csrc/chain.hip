@@ -867,6 +867,81 @@ __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restr
   }
 }
 
+// The fold (xattn_prepare_kernel) and the packing (ffn_pack_kernel) of a short-key cross-attention site in ONE launch: a thread
+// produces one 16-byte unit of the weight stream and computes its eight folded values itself (32-term dot products of the
+// site's projected keys / values with the static projection weights, the same fmaf order as xattn_prepare_kernel: the stream
+// is bit-identical to prepare -> pack).  Nine launches per clip fewer (five text sites, four frame-token layers), two of them
+// per encoder layer on the critical frame-token path.
+__global__ void __launch_bounds__(256) xattn_pack_fused_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                               const float* __restrict__ wqT, const float* __restrict__ wo,
+                                                               unsigned char* __restrict__ out, const int L, const int G,
+                                                               const int P, const long long units, const int single) {
+  constexpr int C = 256, HD = 32, KS = C / 16, NT = C / 32;
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int Hd = 8 * G, NC = Hd / 32;
+  k += (long long)blockIdx.y * L * C;
+  v += (long long)blockIdx.y * L * C;
+  out += (long long)blockIdx.y * units * 16;
+  const int lane = (int)(u & 63);
+  const long long pg = u >> 6;
+  const int piece = (int)(pg % P), it = (int)(pg / P);
+  const int r = lane & 31, hf = lane >> 5;
+  auto dot32 = [](const float* a, const float* b) {
+    const f32x4* ap = reinterpret_cast<const f32x4*>(a);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(b);
+    float acc = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const f32x4 x = ap[c4], y = bp[c4];
+      acc = fmaf(x[0], y[0], acc); acc = fmaf(x[1], y[1], acc); acc = fmaf(x[2], y[2], acc); acc = fmaf(x[3], y[3], acc);
+    }
+    return acc;
+  };
+  u32x4 o = {0u, 0u, 0u, 0u};
+  if (piece == 0) {  // b1 chunk `it`: [hf][16] floats in accumulator order; -1e30 for key slots >= L
+    if (lane < 8 && it < NC) {
+      f32x4 val;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = 4 * lane + c, h2 = idx >> 4, i = idx & 15;
+        const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * h2, h = row / G, j = row - h * G;
+        float a = -1.0e30f;
+        if (j < L) {
+          a = 0.f;
+          for (int c2 = 0; c2 < HD; ++c2) a = fmaf(k[j * C + h * HD + c2], wqT[(long long)C * C + h * HD + c2], a);
+        }
+        val[c] = a;
+      }
+      o = __builtin_bit_cast(u32x4, val);
+    }
+  } else if (piece < 1 + 2 * KS + 4 * NT) {
+    float val[8];
+    int plane;
+    if (piece <= 2 * KS) {  // W1[32 it + r][16 s + 8 hf + j] = sum_c k[key][h*32 + c] * wqT[column][h*32 + c]
+      const int s = (piece - 1) >> 1;
+      plane = (piece - 1) & 1;
+      const int row = 32 * it + r, h = row / G, j = row - h * G;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        val[e] = (it < NC && j < L) ? dot32(k + j * C + h * HD, wqT + (long long)(16 * s + 8 * hf + e) * C + h * HD) : 0.f;
+    } else {  // W2[32 t + r][col] = sum_c wo[n][h*32 + c] * v[key][h*32 + c], col in the accumulator's k order
+      const int q = piece - 1 - 2 * KS;
+      plane = q & 1;
+      const int idx = q >> 1, t = idx >> 1, s2 = idx & 1, chunk = it - 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = 32 * chunk + 16 * s2 + 8 * (e >> 2) + 4 * hf + (e & 3);
+        const int h = col / G, j = col - h * G;
+        val[e] = (chunk >= 0 && chunk < NC && j < L) ? dot32(wo + (long long)(32 * t + r) * C + h * HD, v + j * C + h * HD) : 0.f;
+      }
+    }
+    const HL f = split8(val, single);
+    o = __builtin_bit_cast(u32x4, plane ? f.lo : f.hi);
+  }
+  reinterpret_cast<u32x4*>(out)[u] = o;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 convolution, stride 1, zero padding 1, CIN -> 256 channels, channels-last (the pixel decoder's output
 // convolutions, segmentation.py:186-204,253-283).  Pixel-stationary: a wave owns 32 pixels (the MFMA columns) and all
@@ -1305,6 +1380,20 @@ extern "C" int tce_xattn_prepare_f32(const float* k, const float* v, const float
   hipLaunchKernelGGL(xattn_prepare_kernel, dim3(tce_cdiv(2 * Hd * 256 + Hd, 256), batch), dim3(256), 0, (hipStream_t)stream,
                      k, v, wqT_ext, wo, W1, b1, W2, L, group);
   TCE_CHECK_LAUNCH("tce_xattn_prepare_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_xattn_pack_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, void* packed, int32_t L,
+                                  int32_t group, int32_t batch, tceStream stream) {
+  TCE_CHECK_ARG(k && v && wqT_ext && wo && packed, "tce_xattn_pack_f32: null pointer");
+  TCE_CHECK_ARG((group == 32 || group == 8) && L > 0 && L <= group && batch > 0, "tce_xattn_pack_f32: group must be 32 or 8, 0 < L <= group");
+  TCE_CHECK_ARG(tce_aligned16(k) && tce_aligned16(v) && tce_aligned16(wqT_ext) && tce_aligned16(wo) && tce_aligned16(packed),
+                "tce_xattn_pack_f32: pointers must be 16-byte aligned");
+  const int Hd = 8 * group;
+  const long long units = ffn_units(256, Hd);
+  hipLaunchKernelGGL(xattn_pack_fused_kernel, dim3(tce_cdiv(units, 256), batch), dim3(256), 0, (hipStream_t)stream, k, v, wqT_ext, wo,
+                     (unsigned char*)packed, L, group, ffn_pieces(256), units, tce_gemm_single_pass());
+  TCE_CHECK_LAUNCH("tce_xattn_pack_f32");
   return TCE_OK;
 }
 

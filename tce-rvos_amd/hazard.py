@@ -327,6 +327,10 @@ MODELS = {
          dense(_p(a[3]), 256 * 256 * F)],
         [dense(_p(a[4]), a[9] * 8 * a[8] * 256 * F), dense(_p(a[5]), a[9] * 8 * a[8] * F), dense(_p(a[6]), a[9] * 8 * a[8] * 256 * F)]),
     "tce_xattn_fused_f32": lambda a: _xattn(_st(a[0])),
+    # k, v, wqT, wo, packed, L, group, batch
+    "tce_xattn_pack_f32": lambda a: (
+        [dense(_p(a[0]), a[7] * a[5] * 256 * F), dense(_p(a[1]), a[7] * a[5] * 256 * F), dense(_p(a[2]), 257 * 256 * F), dense(_p(a[3]), 256 * 256 * F)],
+        [dense(_p(a[4]), a[7] * _lib.lib_raw().tce_ffn_packed_bytes(256, 8 * a[6]))]),
     "tce_rowlin_pack_f32": lambda a: ([strided(_p(a[0]), a[4] * F, (a[3], a[1] * F))],
                                       [dense(_p(a[2]), _lib.lib_raw().tce_rowlin_packed_bytes(a[3], a[4]))]),
     "tce_rowlin_f32": lambda a: _rowlin(_st(a[0])),

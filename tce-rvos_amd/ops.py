@@ -1061,6 +1061,7 @@ def conv3x3(x, pk, T, H, W, Cin, N, bias=None, out=None, alloc=None):
 # residual -> LayerNorm is the fused FFN kernel with a grouped softmax as its activation.
 # ---------------------------------------------------------------------------------------------------------------
 XATTN_MIN_ROWS = int(os.environ.get("TCE_XATTN_MIN_ROWS", 4000))
+XATTN_PACK_FUSED = os.environ.get("TCE_XATTN_PACK_FUSED", "1") != "0"
 
 
 def xattn_static(wq, bq, scale=32 ** -0.5):
@@ -1074,6 +1075,11 @@ def xattn_pack(k, v, wqT_ext, wo, L, alloc, group=32, batch=1):
     _chk(k, "k")
     _chk(v, "v")
     Hd = 8 * group
+    if XATTN_PACK_FUSED:  # fold + pack in one launch (bit-identical stream)
+        pk = alloc(batch, lib().tce_ffn_packed_bytes(256, Hd), dtype=torch.uint8)
+        check(lib().tce_xattn_pack_f32(k.data_ptr(), v.data_ptr(), wqT_ext.data_ptr(), wo.data_ptr(), pk.data_ptr(), L, group, batch,
+                                       _stream()), "tce_xattn_pack_f32")
+        return pk
     W1, b1, W2 = alloc(batch, Hd, 256), alloc(batch, Hd), alloc(batch, 256, Hd)
     check(lib().tce_xattn_prepare_f32(k.data_ptr(), v.data_ptr(), wqT_ext.data_ptr(), wo.data_ptr(), W1.data_ptr(), b1.data_ptr(),
                                       W2.data_ptr(), L, group, batch, _stream()), "tce_xattn_prepare_f32")

@@ -968,6 +968,27 @@ def test_xattn_fused(ops, M, L, mode):
     close(out, ref, 3e-4, 3e-4)
 
 
+@pytest.mark.parametrize("L,group,batch", [(32, 32, 1), (9, 32, 1), (8, 8, 5), (5, 8, 2)])
+def test_xattn_pack_one_launch_is_bit_identical(ops, L, group, batch):
+    """tce_xattn_pack_f32 (fold + pack in one launch) against tce_xattn_prepare_f32 -> tce_ffn_pack_batched_f32: the same bytes."""
+    g = torch.Generator().manual_seed(L + group + batch)
+    k, v = dev(torch.randn(batch * L, 256, generator=g)), dev(torch.randn(batch * L, 256, generator=g))
+    wq, bq = dev(torch.randn(256, 256, generator=g) * 0.06), dev(torch.randn(256, generator=g) * 0.2)
+    wo = dev(torch.randn(256, 256, generator=g) * 0.06)
+    wqT = ops.xattn_static(wq, bq)
+    ar = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device="cuda")
+    saved = ops.XATTN_PACK_FUSED
+    try:
+        ops.XATTN_PACK_FUSED = True
+        a = ops.xattn_pack(k, v, wqT, wo, L, ar, group=group, batch=batch)
+        ops.XATTN_PACK_FUSED = False
+        b = ops.xattn_pack(k, v, wqT, wo, L, ar, group=group, batch=batch)
+    finally:
+        ops.XATTN_PACK_FUSED = saved
+    torch.cuda.synchronize()
+    assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_xattn_fused_eight_key_groups_per_frame(ops):
     """FrameTokenLayer's pixel <- token attention (tce_deformable_transformer.py:480-484): every frame has its own 8 keys /
     values, so the folded weights differ per batch entry; softmax over groups of 8 inside a 32-unit chunk."""
