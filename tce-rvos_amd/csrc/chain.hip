@@ -875,18 +875,22 @@ __global__ void __launch_bounds__(256) xattn_prepare_kernel(const float* __restr
 __global__ void __launch_bounds__(256) xattn_pack_fused_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                                const float* __restrict__ wqT, const float* __restrict__ wo,
                                                                unsigned char* __restrict__ out, const int L, const int G,
-                                                               const int P, const long long units, const int single) {
+                                                               const int P, const int SL, const long long threads,
+                                                               const long long units, const int single) {
+  // a thread owns one SLOT of a stage: slot 0 = the bias piece, slot sl >= 1 = the (hi, lo) piece pair 2 sl - 1, 2 sl -- the
+  // eight folded values are computed once and split into both planes (a thread per piece computed every value twice)
   constexpr int C = 256, HD = 32, KS = C / 16, NT = C / 32;
-  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (u >= units) return;
+  const long long tix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (tix >= threads) return;
   const int Hd = 8 * G, NC = Hd / 32;
   k += (long long)blockIdx.y * L * C;
   v += (long long)blockIdx.y * L * C;
   out += (long long)blockIdx.y * units * 16;
-  const int lane = (int)(u & 63);
-  const long long pg = u >> 6;
-  const int piece = (int)(pg % P), it = (int)(pg / P);
+  const int lane = (int)(tix & 63);
+  const long long sg = tix >> 6;
+  const int sl = (int)(sg % SL), it = (int)(sg / SL);
   const int r = lane & 31, hf = lane >> 5;
+  u32x4* const stage_out = reinterpret_cast<u32x4*>(out) + (long long)it * P * 64;
   auto dot32 = [](const float* a, const float* b) {
     const f32x4* ap = reinterpret_cast<const f32x4*>(a);
     const f32x4* bp = reinterpret_cast<const f32x4*>(b);
@@ -898,8 +902,8 @@ __global__ void __launch_bounds__(256) xattn_pack_fused_kernel(const float* __re
     }
     return acc;
   };
-  u32x4 o = {0u, 0u, 0u, 0u};
-  if (piece == 0) {  // b1 chunk `it`: [hf][16] floats in accumulator order; -1e30 for key slots >= L
+  if (sl == 0) {  // b1 chunk `it`: [hf][16] floats in accumulator order; -1e30 for key slots >= L
+    u32x4 o = {0u, 0u, 0u, 0u};
     if (lane < 8 && it < NC) {
       f32x4 val;
 #pragma unroll
@@ -915,20 +919,22 @@ __global__ void __launch_bounds__(256) xattn_pack_fused_kernel(const float* __re
       }
       o = __builtin_bit_cast(u32x4, val);
     }
-  } else if (piece < 1 + 2 * KS + 4 * NT) {
+    stage_out[lane] = o;
+    return;
+  }
+  const int p_hi = 2 * sl - 1, p_lo = 2 * sl;  // pieces of this slot
+  if (p_hi >= P) return;
+  u32x4 oh = {0u, 0u, 0u, 0u}, ol = oh;
+  if (p_hi < 1 + 2 * KS + 4 * NT) {
     float val[8];
-    int plane;
-    if (piece <= 2 * KS) {  // W1[32 it + r][16 s + 8 hf + j] = sum_c k[key][h*32 + c] * wqT[column][h*32 + c]
-      const int s = (piece - 1) >> 1;
-      plane = (piece - 1) & 1;
+    if (p_hi <= 2 * KS) {  // W1[32 it + r][16 s + 8 hf + e] = sum_c k[key][h*32 + c] * wqT[column][h*32 + c]
+      const int s = (p_hi - 1) >> 1;
       const int row = 32 * it + r, h = row / G, j = row - h * G;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         val[e] = (it < NC && j < L) ? dot32(k + j * C + h * HD, wqT + (long long)(16 * s + 8 * hf + e) * C + h * HD) : 0.f;
     } else {  // W2[32 t + r][col] = sum_c wo[n][h*32 + c] * v[key][h*32 + c], col in the accumulator's k order
-      const int q = piece - 1 - 2 * KS;
-      plane = q & 1;
-      const int idx = q >> 1, t = idx >> 1, s2 = idx & 1, chunk = it - 1;
+      const int idx = (p_hi - 1 - 2 * KS) >> 1, t = idx >> 1, s2 = idx & 1, chunk = it - 1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int col = 32 * chunk + 16 * s2 + 8 * (e >> 2) + 4 * hf + (e & 3);
@@ -937,9 +943,11 @@ __global__ void __launch_bounds__(256) xattn_pack_fused_kernel(const float* __re
       }
     }
     const HL f = split8(val, single);
-    o = __builtin_bit_cast(u32x4, plane ? f.lo : f.hi);
+    oh = __builtin_bit_cast(u32x4, f.hi);
+    ol = __builtin_bit_cast(u32x4, f.lo);
   }
-  reinterpret_cast<u32x4*>(out)[u] = o;
+  stage_out[p_hi * 64 + lane] = oh;
+  if (p_lo < P) stage_out[p_lo * 64 + lane] = ol;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1391,8 +1399,10 @@ extern "C" int tce_xattn_pack_f32(const float* k, const float* v, const float* w
                 "tce_xattn_pack_f32: pointers must be 16-byte aligned");
   const int Hd = 8 * group;
   const long long units = ffn_units(256, Hd);
-  hipLaunchKernelGGL(xattn_pack_fused_kernel, dim3(tce_cdiv(units, 256), batch), dim3(256), 0, (hipStream_t)stream, k, v, wqT_ext, wo,
-                     (unsigned char*)packed, L, group, ffn_pieces(256), units, tce_gemm_single_pass());
+  const int P = ffn_pieces(256), SL = 1 + P / 2;           // slot 0 = piece 0, slot sl = pieces 2 sl - 1, 2 sl
+  const long long threads = (long long)(Hd / 32 + 2) * SL * 64;
+  hipLaunchKernelGGL(xattn_pack_fused_kernel, dim3(tce_cdiv(threads, 256), batch), dim3(256), 0, (hipStream_t)stream, k, v, wqT_ext,
+                     wo, (unsigned char*)packed, L, group, P, SL, threads, units, tce_gemm_single_pass());
   TCE_CHECK_LAUNCH("tce_xattn_pack_f32");
   return TCE_OK;
 }

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
 // splits > 1 / bias: qkv is given as `splits` partial planes [L, 3E] (split-K partial sums, plane stride L*3E) + a bias [3E]:
 // the reduction of the projection rides in this kernel's loads (no reduce launch between projection and attention).
 template <int HDIM, int LMAX>
-__global__ void __launch_bounds__(128) mha_small_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
+__global__ void __launch_bounds__(256) mha_small_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
                                                         int nheads, float scale, int splits, const float* __restrict__ bias) {
   __shared__ __attribute__((aligned(16))) float sK[LMAX * HDIM];
   __shared__ __attribute__((aligned(16))) float sV[LMAX * HDIM];
@@ -72,13 +72,15 @@ __global__ void __launch_bounds__(128) mha_small_kernel(const float* __restrict_
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
     return v;
   };
-  for (int i = tid; i < L * (HDIM / 4); i += 128) {
+  // 256 threads stage K / V (with partial planes that is three times the loads); the upper 128 leave after the barrier
+  for (int i = tid; i < L * (HDIM / 4); i += 256) {
     const int j = i / (HDIM / 4), d4 = i % (HDIM / 4);
     const float* p = qkv + (long long)j * 3 * E + h * HDIM + d4 * 4;
     *reinterpret_cast<f32x4*>(&sK[j * HDIM + d4 * 4]) = ld4(p + E, E + h * HDIM + d4 * 4);
     *reinterpret_cast<f32x4*>(&sV[j * HDIM + d4 * 4]) = ld4(p + 2 * E, 2 * E + h * HDIM + d4 * 4);
   }
   __syncthreads();
+  if (tid >= 128) return;
   // four lanes per query (a quarter of the head dim each): the score is a 16-term partial dot + two shuffles, the output
   // row is split the same way -- a thread per query walked the keys with 128 dependent FMAs each (19 us for 32 tokens)
   constexpr int QD = HDIM / 4;
@@ -156,7 +158,7 @@ extern "C" int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int3
   TCE_CHECK_ARG(qkv && out && nheads > 0, "tce_mha_small64_f32: bad arguments");
   TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_f32: sequence length %d outside 1..128", L);
   TCE_CHECK_ARG(tce_aligned16(qkv) && tce_aligned16(out), "tce_mha_small64_f32: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(128), 0, (hipStream_t)stream, qkv, out, L,
+  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(256), 0, (hipStream_t)stream, qkv, out, L,
                      nheads, scale, 1, (const float*)nullptr);
   TCE_CHECK_LAUNCH("tce_mha_small64_f32");
   return TCE_OK;
@@ -168,7 +170,7 @@ extern "C" int tce_mha_small64_splits_f32(const float* qkv_planes, int32_t split
   TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_splits_f32: sequence length %d outside 1..128", L);
   TCE_CHECK_ARG(tce_aligned16(qkv_planes) && tce_aligned16(out) && (!bias || tce_aligned16(bias)),
                 "tce_mha_small64_splits_f32: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(128), 0, (hipStream_t)stream, qkv_planes, out,
+  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(256), 0, (hipStream_t)stream, qkv_planes, out,
                      L, nheads, scale, splits, bias);
   TCE_CHECK_LAUNCH("tce_mha_small64_splits_f32");
   return TCE_OK;

@@ -175,10 +175,17 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             else:
                 text_hidden, text_pooled = text_in(tA) if callable(text_in) else text_in
             L = text_hidden.shape[0]
-            tmp = _lin(tA, text_hidden, L, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-            text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
-            tmp = _lin(tA, text_pooled, 1, cfg.text_hidden, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-            sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
+            TH = cfg.text_hidden
+            if text_pooled.data_ptr() == text_hidden.data_ptr() + L * TH * 4 and text_hidden.is_contiguous():
+                # the text plan hands hidden states and pooled vector over as one [L + 1, 768] tensor: one resizer launch pair
+                tmp = _lin(tA, text_hidden, L + 1, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                both = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L + 1, D))
+                text, sent = both[:L], both[L:]
+            else:
+                tmp = _lin(tA, text_hidden, L, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
+                tmp = _lin(tA, text_pooled, 1, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
             text_pos = model._text_pos(L, dev)
             xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
 
@@ -540,24 +547,34 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         nl = cfg.dec_layers
         hs = A(nl, T * Q, D)
         inter_ref = A(nl, T * Q, 4)
+        logits = A(nl, T * Q, cfg.num_classes)
+        logits_done = [False] * nl
         qpos = w["query_embed.weight"]  # [Q, D], shared by all frames
-        r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
-        init_ref = ops.tile(ops.sigmoid(r, out=A(Q, 2)), T, out=A(T * Q, 2))
+        if few(Q, "dec"):  # Linear + sigmoid in one launch
+            r = A(Q, 2)
+            FR(qpos, Q, D, [(w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], r, 2, 2, False, ops.FR_SIGMOID)])
+        else:
+            r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
+            r = ops.sigmoid(r, out=A(Q, 2))
+        init_ref = ops.tile(r, T, out=A(T * Q, 2))
         tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
         ref, ref_dim = init_ref, 2
         for lid in range(0 if "decoder" not in ABLATE else nl, nl):
             lp = f"transformer.decoder.layers.{lid}."
             m0 = dar.mark()
             pre = lp + "self_attn."
+            # the layer works in hs[lid]: its first write (self-attention output + residual) goes there with the previous
+            # layer's output as the residual, everything after is in place -- no copy of the layer's result into hs
+            prev, tgt = tgt, hs[lid]
             qk = A(T * Q, 2 * D)
             if few(T * Q, "dec"):
                 v = A(T * Q, D)
-                FR(tgt, T * Q, D, [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
-                                   (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=qpos, lda2=D, a2_rows=Q)
+                FR(prev, T * Q, D, [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
+                                    (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=qpos, lda2=D, a2_rows=Q)
             else:
-                gemm_ex(tgt, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
+                gemm_ex(prev, w[pre + "qk.w"], qk, Q, 2 * D, D, D, D, 2 * D, bias=w[pre + "qk.b"], a2=qpos, lda2=D, batch=T,
                         sA=Q * D, sA2=0, sC=Q * 2 * D)
-                v = _lin(A, tgt, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                v = _lin(A, prev, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(T * Q, D)
             if cfg.qtrans:
                 # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
@@ -566,9 +583,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
             if few(T * Q, "dec"):
                 FR(att, T * Q, D, [(w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, D, D, False, ops.FR_NONE)],
-                   res=tgt, ldres=D)
+                   res=prev, ldres=D)
             else:
-                gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
+                gemm_ex(att, w[pre + "out_proj.weight"], tgt, T * Q, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=prev,
                         ldres=D, res_mode=RES_ADD)
             ln_(tgt, lp + "norm2")
             msda(lp + "cross_attn.", tgt, T * Q, Q, qpos, True, memory, ref, ref_dim, True, tgt, ar=dar, norm=lp + "norm1",
@@ -579,7 +596,11 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 t1, t2 = A(T * Q, D), A(T * Q, D)
                 if few(T * Q, "dec"):
                     t3 = A(T * Q, 4)
-                    FR(tgt, T * Q, D, [(w[bp + "0.weight"], w[bp + "0.bias"], t1, D, D, False, ops.FR_RELU)])
+                    # the level's class head reads the same rows: it rides in the box MLP's first launch
+                    FR(tgt, T * Q, D, [(w[bp + "0.weight"], w[bp + "0.bias"], t1, D, D, False, ops.FR_RELU),
+                                       (w[f"class_embed.{lid}.weight"], w[f"class_embed.{lid}.bias"], logits[lid], cfg.num_classes,
+                                        cfg.num_classes, False, ops.FR_NONE)])
+                    logits_done[lid] = True
                     FR(t1, T * Q, D, [(w[bp + "1.weight"], w[bp + "1.bias"], t2, D, D, False, ops.FR_RELU)])
                     FR(t2, T * Q, D, [(w[bp + "2.weight"], w[bp + "2.bias"], t3, 4, 4, False, ops.FR_NONE)])
                 else:
@@ -589,13 +610,13 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 ops.box_refine(t3, ref, out=inter_ref[lid])
                 ref, ref_dim = inter_ref[lid], 4
             dar.release(m0)
-            ops.tile(tgt, 1, out=hs[lid])
 
         # ------------------------------------------------------------------ heads (:330-365)
         # with box refinement bbox_embed[l] IS transformer.decoder.bbox_embed[l] (tce_rvos.py:124), so
         # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(ref_{l-1})) is exactly inter_ref[l].
-        logits = A(nl, T * Q, cfg.num_classes)
         for lvl in range(nl):
+            if logits_done[lvl]:
+                continue
             ci = lvl if cfg.with_box_refine else 0  # without refinement one head is shared by all levels (:127-130)
             gemm_ex(hs[lvl], w[f"class_embed.{ci}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
                     bias=w[f"class_embed.{ci}.bias"])

@@ -43,7 +43,8 @@ class TextPlan:
         split-K GEMM: 12.7 vs 9.8 us, profiles/r03_fewrow.txt.)"""
         sd, C, L = self.sd, self.C, ids.shape[1]
         s = ops._stream()
-        x = A(L, C)
+        xbuf = A(L + 1, C)  # row L receives the pooler output: hidden states and pooled vector are ONE [L + 1, C] tensor for the
+        x = xbuf[:L]         # resizer (one projection + one LayerNorm launch for both, pipeline.text_stage)
         # position ids (HF create_position_ids_from_input_ids) are derived inside the kernel: no ATen arithmetic here
         check(lib().tce_embed_ln_f32(ids.data_ptr(), None, sd["embeddings.word_embeddings.weight"].data_ptr(),
                                      sd["embeddings.position_embeddings.weight"].data_ptr(),
@@ -74,7 +75,7 @@ class TextPlan:
                                   bias_x=sd[p + "intermediate.dense.bias"], act_x=ACT_GELU)
                 ops.splitk_reduce(ws_b, t_f2, L, C, x, bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
                                   ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]), eps=self.eps)
-            return self._pooler(x, A, s)
+            return self._pooler(x, xbuf[L], s)
         ws = A(max(sk_qkv * L * 3 * C, sk_out * L * C, sk_f1 * L * self.ff, sk_f2 * L * C))
         for wqkv, bqkv, p in self.layers:
             gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
@@ -88,11 +89,10 @@ class TextPlan:
             gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
                     bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws, ln_eps=self.eps,
                     ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]))
-        return self._pooler(x, A, s)
+        return self._pooler(x, xbuf[L], s)
 
-    def _pooler(self, x, A, s):
+    def _pooler(self, x, pooled, s):
         sd, C = self.sd, self.C
-        pooled = A(C)
         gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])
         check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), C, s), "tce_tanh_f32")
         return x, pooled
