@@ -801,7 +801,12 @@ class ReferFormer(nn.Module):
         torch.cuda.synchronize()
         keep = os.environ.get("TCE_KEEP_GRAPHS", "0") == "1"  # keep the hipGraph_t beside the executable (clip groups)
         graph = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # capture_error_mode="thread_local": under the default ("global") mode ANY thread's event query is an error while this
+        # thread captures -- and torch.distributed's RCCL watchdog thread polls the events of in-flight collectives (bench.py keeps
+        # the previous step's all-gather in flight): it then dies with "operation not permitted when stream is capturing" and takes
+        # the process down (seen once in round 4, test_rccl_world1_bench_path_executes_the_collective).  This thread itself calls
+        # nothing capture-unsafe: arenas and side streams exist before the capture starts.
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = fn(res)
         if keep:
             graph.instantiate()
