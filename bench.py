@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--ranks-per-gpu", type=int, default=1,
                     help="processes sharing one GPU (rank r runs on cuda:(LOCAL_RANK // R)): each process has its own HIP "
                          "hardware queues, which one process's graph replays do not (DESIGN.md section 6)")
+    ap.add_argument("--group", type=int, default=1,
+                    help="clips per forward as ONE launch program (model.forward_group): independent clips, block-diagonal across "
+                         "clips, each clip's result = its B=1 forward's; the latency-bound stages are shared by the group")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1 without the per-step mask all-gather (barrier + max-over-ranks timing only): isolates the "
                          "compute side of a ranks-per-GPU measurement from gloo's host-side copies")
@@ -181,21 +184,28 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(C, 4))]
     use_host_ids = False  # the text-cache pass keys the cache on host ids
 
+    Gp = max(1, args.group)
+    ids_groups = [torch.cat([ids[(k + j) % n_pool] for j in range(Gp)], 0) for k in range(n_pool)] if Gp > 1 else None
+
     def one(i, slot=0):
+        """the forward(s) of one unit of a step: a list of per-clip output dicts (Gp of them for a clip group)"""
+        if Gp > 1:
+            k = (i * Gp) % n_pool
+            return model.forward_group([clips[(k + j) % n_pool] for j in range(Gp)], ids_groups[k], targets, slot=slot)
         tok = ids_host[i % n_pool] if use_host_ids else ids[i % n_pool]
-        return model([clips[i % n_pool]], tok, targets, slot=slot)
+        return [model([clips[i % n_pool]], tok, targets, slot=slot)]
 
     def step(i, gather=True):
         nonlocal gather_buf, pending
         if C == 1:
-            outs = [one(i)]
-        else:  # C independent B=1 forwards in flight, one per stream / replay slot
+            outs = one(i)
+        else:  # C independent forwards in flight, one per stream / replay slot
             cur = torch.cuda.current_stream()
             outs = []
             for c in range(C):
                 streams[c].wait_stream(cur)
                 with torch.cuda.stream(streams[c]):
-                    outs.append(one(i * C + c, slot=c))
+                    outs.extend(one(i * C + c, slot=c))
             for c in range(C):
                 cur.wait_stream(streams[c])
         if dist_on and gather and not args.no_gather:
@@ -205,7 +215,7 @@ def main():
             local = torch.stack([ops.select_masks(o["pred_logits"][0], o["pred_masks"][0], (H, W))[0] for o in outs], 0)
             if pending is not None:
                 gather_buf = pending.wait()
-            pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C, force=force_dist)
+            pending = gather_clip_masks_async(local if args.backend == "nccl" else local.cpu(), world * C * Gp, force=force_dist)
             last_local[0] = local
         return outs[0]
 
@@ -232,8 +242,8 @@ def main():
     collective = None
     if dist_on and not args.no_gather:
         # the last step's gathered masks must hold this rank's block at this rank's place (checked on every rank)
-        lo = rank * C
-        ok = gather_buf is not None and bool((gather_buf[lo:lo + C].to(last_local[0].device) == last_local[0]).all())
+        lo = rank * C * Gp
+        ok = gather_buf is not None and bool((gather_buf[lo:lo + C * Gp].to(last_local[0].device) == last_local[0]).all())
         collective = {"backend": dist.get_backend(), "world": world, "forced_world1": bool(force_dist and world == 1),
                       "bytes_per_rank_per_step": int(last_local[0].numel() * last_local[0].element_size()),
                       "gathered_shape": list(gather_buf.shape), "own_block_matches": ok}
@@ -247,6 +257,7 @@ def main():
 
     roofline, roofline_hbm = None, None
     C_saved, C = C, 1  # the instrumented pass, the variants and the parity check run one clip at a time
+    Gp_saved, Gp = Gp, 1
     solo = rank == 0 and world == 1 and not force_dist
     if rank == 0 and not args.no_roofline:
         n_inst = min(args.steps, 40)
@@ -340,6 +351,13 @@ def main():
                 C = cc
                 variants[f"value_c{cc}"] = round(n_var * cc / timed(n_var, 4, gather=False), 3)
             C = 1
+        if model.use_graph and C_saved == 1 and Gp_saved == 1 and args.gemm_mode != "f32":
+            # clip groups (model.forward_group): G independent clips as ONE launch program, each clip's result its B = 1 forward's
+            for gg in (2, 4):
+                Gp = gg
+                ids_groups = [torch.cat([ids[(k + j) % n_pool] for j in range(Gp)], 0) for k in range(n_pool)]
+                variants[f"value_group{gg}"] = round(n_var * gg / timed(n_var, 4, gather=False), 3)
+            Gp = 1
         model.text_cache_size, use_host_ids = 8, True
         variants["value_text_cached"] = round(n_var / timed(n_var, 6, gather=False), 3)
         model.text_cache_size, use_host_ids = 0, False
@@ -396,14 +414,14 @@ def main():
     if parity is not None and not parity["criterion_met"]:
         print(f"bench.py: PARITY FAILURE: mask IoU vs the oracle {parity['mask_iou_vs_oracle']} misses the 1e-3 criterion in this "
               f"arithmetic ({args.gemm_mode}, policy {args.arith_policy}): the throughput below is NOT a valid result", file=sys.stderr)
-    C = C_saved
+    C, Gp = C_saved, Gp_saved
     if rank == 0:
         known = {("resnet50", 1, 360, 640): "BASELINE config 1", ("swin_t_p4w7", 5, 360, 640): "BASELINE config 2",
                  ("video_swin_t_p4w7", 8, 384, 640): "BASELINE config 3", ("swin_b_p4w7", 10, 480, 854): "BASELINE config 5"}
         cfg_name = known.get((args.backbone, T, H, W), "not a BASELINE config")
         metric = METRIC if cfg_name == "BASELINE config 2" else \
             f"clips/s (T={T}, {H}×{W}, {args.backbone}; {cfg_name}) at {world} MI355X; mask IoU vs ref"
-        clips_total = args.steps * world * C
+        clips_total = args.steps * world * C * Gp
         line = {"metric": metric, "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": (world + args.ranks_per_gpu - 1) // args.ranks_per_gpu,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "timed_region_s": round(elapsed, 3),
@@ -415,7 +433,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
-                           "clips_per_step": world * C, "clips_in_flight_per_gpu": C,
+                           "clips_per_step": world * C * Gp, "clips_in_flight_per_gpu": C, "clips_per_forward": Gp,
                            "ranks_per_gpu": args.ranks_per_gpu,
                            "parallelism": f"clip-sharded x{world}" +
                                           ((" + harness kernel + " + ("RCCL" if args.backend == "nccl" else "gloo") +

@@ -265,6 +265,10 @@ int tce_resize_v_norm_f32(const uint8_t* tmp, const int32_t* coef, const int32_t
 int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                      const float* gamma, const float* beta, float* out, int32_t L, int32_t C, float eps, int32_t pad_id,
                      tceStream stream);
+/* Several captions of equal length in one launch (clip groups): ids [nseq * seq_len], position ids restart per caption. */
+int tce_embed_ln_seqs_f32(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                          const float* beta, float* out, int32_t nseq, int32_t seq_len, int32_t C, float eps, int32_t pad_id,
+                          tceStream stream);
 int tce_mha_small64_f32(const float* qkv, float* out, int32_t L, int32_t nheads, float scale, tceStream stream);
 int tce_tanh_f32(const float* x, float* out, int64_t n, tceStream stream);
 
@@ -286,6 +290,10 @@ int tce_splitk_reduce_f32(const float* ws, int32_t splits, int32_t M, int32_t N,
                           tceStream stream);
 int tce_mha_small64_splits_f32(const float* qkv_planes, int32_t splits, const float* bias, float* out, int32_t L, int32_t nheads,
                                float scale, tceStream stream);
+/* The same for nseq sequences of L tokens stacked as [nseq * L, 3E] rows (planes of [nseq * L, 3E]): attention inside each
+ * sequence only (several captions of one clip group). */
+int tce_mha_small64_seqs_f32(const float* qkv_planes, int32_t splits, const float* bias, float* out, int32_t nseq, int32_t L,
+                             int32_t nheads, float scale, tceStream stream);
 
 /* Fused FFN / MLP, the hidden tensor kept on chip (csrc/chain.hip):
  *     out[M,C] = LN_out?( x + W2 act( W1 LN_in?(x) + b1 ) + b2 )        act 1 ReLU | 2 GELU(erf)
@@ -374,6 +382,8 @@ typedef struct {
   int64_t sX, sRes, sOut, sW;
   int32_t M, batch, a2_rows, res_mode, group;
   float eps_out;
+  int32_t w_div; /* batch entries sharing one weight stream: entry b reads stream b / w_div (0 or 1: one stream per entry when sW != 0).
+                    Clip groups: the T frames of a clip share the clip's text keys (VisionLanguageFusionModule per level). */
 } tceXattnArgs;
 int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
                           float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream);

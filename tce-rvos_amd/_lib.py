@@ -37,7 +37,7 @@ class XattnArgs(C.Structure):
                 ("g_out", c_f), ("be_out", c_f),
                 ("ldx", i64), ("lda2", i64), ("ldres", i64), ("ldo", i64),
                 ("sX", i64), ("sRes", i64), ("sOut", i64), ("sW", i64),
-                ("M", i32), ("batch", i32), ("a2_rows", i32), ("res_mode", i32), ("group", i32), ("eps_out", f32)]
+                ("M", i32), ("batch", i32), ("a2_rows", i32), ("res_mode", i32), ("group", i32), ("eps_out", f32), ("w_div", i32)]
 
 
 
@@ -101,6 +101,8 @@ SIGNATURES = {
     "tce_select_masks_u8": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, f32, c_f]),
     "tce_embed_ln_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, f32, i32, c_f]),
     "tce_mha_small64_f32": (i32, [c_f, c_f, i32, i32, f32, c_f]),
+    "tce_mha_small64_seqs_f32": (i32, [c_f, i32, c_f, c_f, i32, i32, i32, f32, c_f]),
+    "tce_embed_ln_seqs_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, f32, i32, c_f]),
     "tce_tanh_f32": (i32, [c_f, c_f, i64, c_f]),
     "tce_ffn_packed_bytes": (i64, [i32, i32]),
     "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),

@@ -264,6 +264,7 @@ struct FfnArgs {
   float eps_in, eps_out;
   int* range_flag;  // tce_set_range_flag: set when a hidden or an output value leaves the fp16 range of the split
   int single;       // tce_set_gemm_mode(2): one MFMA per product on nearest-rounded fp16 operands
+  int wdiv;         // batch entries (grid.y) sharing one weight stream: stream index = blockIdx.y / wdiv (>= 1)
 };
 
 template <int C, int WAVES, int ACT>
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   // this wave's pieces are wave, wave + WAVES, ... of every block, and blocks are contiguous: the source pointer
   // simply advances by WAVES pieces per DMA for the whole kernel (the stream ends with one block of padding, so the
   // last iteration's prefetch reads defined bytes that are never consumed)
-  const unsigned char* wp = p.wpk + blockIdx.y * p.sW + (long long)wave * PIECE;
+  const unsigned char* wp = p.wpk + (long long)(blockIdx.y / p.wdiv) * p.sW + (long long)wave * PIECE;
   const unsigned voff = lane * 16;
   const unsigned wbase = wave * PIECE;
   auto dma = [&](int stage, int q) {
@@ -1368,6 +1369,7 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2; a.res_mode = 1;
   a.g_in = g_in; a.be_in = be_in; a.g_out = g_out; a.be_out = be_out;
   a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  a.wdiv = 1;
   hipStream_t s = (hipStream_t)stream;
   if (C == 256) ffn_launch<256, 4>(a, act, s);
   else if (C == 192) ffn_launch<192, 4>(a, act, s);
@@ -1426,6 +1428,7 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   a.ldx = q.ldx; a.ldo = q.ldo; a.a2 = q.a2; a.lda2 = q.lda2; a.a2_rows = q.a2_rows; a.res = q.res; a.ldres = q.ldres;
   a.res_mode = q.res_mode; a.sX = q.sX; a.sRes = q.sRes; a.sOut = q.sOut; a.sW = q.sW;
   a.M = q.M; a.NI = (8 * q.group) / 32 + 1; a.eps_out = q.eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  a.wdiv = q.w_div > 0 ? q.w_div : 1;
   const int batch = q.batch > 0 ? q.batch : 1;
   const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
   if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3>), grid, block, 0, (hipStream_t)stream, a);

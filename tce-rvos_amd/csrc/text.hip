@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ out, int L,
-                                                       int C, float eps, int pad_id) {
+                                                       int C, float eps, int pad_id, int seq_len) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= L) return;
@@ -18,9 +18,10 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
   if (pos_ids) {
     pid = pos_ids[tok];
   } else {
-    // HF create_position_ids_from_input_ids: pad + (number of non-pad tokens up to and including this one), pad -> pad
+    // HF create_position_ids_from_input_ids: pad + (number of non-pad tokens up to and including this one), pad -> pad;
+    // seq_len: the L tokens are L / seq_len captions of equal length, the count restarts at each caption
     int cnt = 0;
-    for (int i = lane; i <= tok; i += 64) cnt += ids[i] != pad_id;
+    for (int i = (tok / seq_len) * seq_len + lane; i <= tok; i += 64) cnt += ids[i] != pad_id;
     cnt = (int)wave_sum((float)cnt);
     pid = ids[tok] != pad_id ? pad_id + cnt : pad_id;
   }
@@ -60,12 +61,15 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
 template <int HDIM, int LMAX>
 __global__ void __launch_bounds__(256) mha_small_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
                                                         int nheads, float scale, int splits, const float* __restrict__ bias) {
+  // gridDim.z sequences of L tokens stacked as rows: sequence z owns rows z*L .. z*L + L - 1 of every plane and of `out`
   __shared__ __attribute__((aligned(16))) float sK[LMAX * HDIM];
   __shared__ __attribute__((aligned(16))) float sV[LMAX * HDIM];
   const int h = blockIdx.x;
   const int E = nheads * HDIM;
   const int tid = threadIdx.x;
-  const long long plane = (long long)L * 3 * E;
+  const long long plane = (long long)L * gridDim.z * 3 * E;
+  qkv += (long long)blockIdx.z * L * 3 * E;
+  out += (long long)blockIdx.z * L * E;
   auto ld4 = [&](const float* p, int col) {  // sum of the partial planes (+ bias) at p
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
     for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(p + s * plane);
@@ -148,8 +152,20 @@ extern "C" int tce_embed_ln_f32(const int64_t* ids, const int64_t* pos_ids, cons
   TCE_CHECK_ARG(ids && word && pos && type0 && gamma && beta && out && L > 0 && C > 0 && C % 4 == 0,
                 "tce_embed_ln_f32: bad arguments");
   hipLaunchKernelGGL(embed_ln_kernel, dim3(tce_cdiv(L, 4)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
-                     type0, gamma, beta, out, L, C, eps, pad_id);
+                     type0, gamma, beta, out, L, C, eps, pad_id, L);
   TCE_CHECK_LAUNCH("tce_embed_ln_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_embed_ln_seqs_f32(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                                     const float* beta, float* out, int32_t nseq, int32_t seq_len, int32_t C, float eps, int32_t pad_id,
+                                     tceStream stream) {
+  TCE_CHECK_ARG(ids && word && pos && type0 && gamma && beta && out && nseq > 0 && seq_len > 0 && C > 0 && C % 4 == 0,
+                "tce_embed_ln_seqs_f32: bad arguments");
+  const int L = nseq * seq_len;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(tce_cdiv(L, 4)), dim3(256), 0, (hipStream_t)stream, ids, (const int64_t*)nullptr, word, pos,
+                     type0, gamma, beta, out, L, C, eps, pad_id, seq_len);
+  TCE_CHECK_LAUNCH("tce_embed_ln_seqs_f32");
   return TCE_OK;
 }
 
@@ -173,6 +189,18 @@ extern "C" int tce_mha_small64_splits_f32(const float* qkv_planes, int32_t split
   hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32)), dim3(256), 0, (hipStream_t)stream, qkv_planes, out,
                      L, nheads, scale, splits, bias);
   TCE_CHECK_LAUNCH("tce_mha_small64_splits_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_mha_small64_seqs_f32(const float* qkv_planes, int32_t splits, const float* bias, float* out, int32_t nseq, int32_t L,
+                                        int32_t nheads, float scale, tceStream stream) {
+  TCE_CHECK_ARG(qkv_planes && out && nheads > 0 && splits >= 1 && splits <= 64 && nseq > 0 && nseq <= 64, "tce_mha_small64_seqs_f32: bad arguments");
+  TCE_CHECK_ARG(L > 0 && L <= 128, "tce_mha_small64_seqs_f32: sequence length %d outside 1..128", L);
+  TCE_CHECK_ARG(tce_aligned16(qkv_planes) && tce_aligned16(out) && (!bias || tce_aligned16(bias)),
+                "tce_mha_small64_seqs_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL((mha_small_kernel<64, 128>), dim3(nheads, tce_cdiv(L, 32), nseq), dim3(256), 0, (hipStream_t)stream, qkv_planes,
+                     out, L, nheads, scale, splits, bias);
+  TCE_CHECK_LAUNCH("tce_mha_small64_seqs_f32");
   return TCE_OK;
 }
 

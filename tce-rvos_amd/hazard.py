@@ -146,8 +146,9 @@ def _xattn(q):
     b = max(1, q.batch)
     L = _lib.lib_raw()
     nb = L.tce_ffn_packed_bytes(256, 8 * q.group)
+    wd = q.w_div if q.w_div > 0 else 1
     rd = [strided(_p(q.x), 256 * F, (b, q.sX * F), (q.M, q.ldx * F)),
-          strided(_p(q.packed), nb, (b if q.sW else 1, q.sW)), dense(_p(q.bo), 256 * F)]
+          strided(_p(q.packed), nb, ((b + wd - 1) // wd if q.sW else 1, q.sW)), dense(_p(q.bo), 256 * F)]
     if q.a2:
         rd.append(strided(_p(q.a2), 256 * F, (q.a2_rows if q.a2_rows > 0 else q.M, q.lda2 * F)))
     if q.res:
@@ -354,6 +355,12 @@ MODELS = {
     # planes, splits, bias, out, L, nheads
     "tce_mha_small64_splits_f32": lambda a: ([dense(_p(a[0]), a[1] * a[4] * 3 * a[5] * 64 * F), dense(_p(a[2]), 3 * a[5] * 64 * F)],
                                              [dense(_p(a[3]), a[4] * a[5] * 64 * F)]),
+    # planes, splits, bias, out, nseq, L, nheads
+    "tce_mha_small64_seqs_f32": lambda a: ([dense(_p(a[0]), a[1] * a[4] * a[5] * 3 * a[6] * 64 * F), dense(_p(a[2]), 3 * a[6] * 64 * F)],
+                                           [dense(_p(a[3]), a[4] * a[5] * a[6] * 64 * F)]),
+    # ids, word, pos, type0, gamma, beta, out, nseq, seq_len, C
+    "tce_embed_ln_seqs_f32": lambda a: ([dense(_p(a[0]), a[7] * a[8] * 8), dense(_p(a[4]), a[9] * F), dense(_p(a[5]), a[9] * F)],
+                                        [dense(_p(a[6]), a[7] * a[8] * a[9] * F)]),
     "tce_swin_attn_pack_f32": lambda a: ([dense(_p(a[0]), 3 * a[3] * a[3] * F), dense(_p(a[1]), a[3] * a[3] * F)],
                                          [dense(_p(a[2]), _lib.lib_raw().tce_swin_attn_packed_bytes(a[3]))]),
     # x, ldx, packed, qkv_bias, proj_bias, table, g1, be1, eps, out, ldo, T, H, W, C, shift

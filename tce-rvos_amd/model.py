@@ -619,6 +619,80 @@ class ReferFormer(nn.Module):
         ops.range_snapshot_async(frames.device)
         return self._tag_diagnostics(out)
 
+    @torch.no_grad()
+    def forward_group(self, clips, captions, targets, slot=0):
+        """G independent clips in ONE launch program (an extension; `forward` is the reference's boundary).
+
+        clips: list of G tensors [T,3,H,W] of the SAME shape on the GPU; captions: LongTensor [G, L] of token ids, or a list of G
+        strings that tokenise to the same length; targets: [{'size': (H, W)}] (one entry, or G equal ones).  Returns a list of G
+        output dicts, each what `forward([clip], caption, targets)` returns for that clip (same keys / shapes; values to fp32
+        round-off: a launch with more rows may pick another split-K factor).  The clips do NOT interact -- the stages that look
+        across a clip's frames or at its caption are block-diagonal per clip (pipeline._run_clip) -- unlike the reference's own
+        batch dimension, which mixes the clips of a batch.  Why: a clip alone leaves the GPU latency-bound for a third
+        of its time (Swin stages 3-4 at 4600 rows, the text branch, the token / decoder paths); G clips share those launches:
+        DESIGN section 3.10 has the measured clips/s.  Video-Swin's 3-D windows span a clip's frames: its window kernel is launched
+        per clip, everything else is shared.  Limits: un-padded clips, G * L <= 128 caption tokens, the split-fp16 arithmetic."""
+        G = len(clips)
+        if G == 1:
+            cap = captions[:1] if torch.is_tensor(captions) else [captions[0]]
+            return [self.forward([clips[0]], cap, targets[:1], slot=slot)]
+        shp = tuple(clips[0].shape)
+        if any(tuple(c.shape) != shp or not c.is_cuda for c in clips) or len(shp) != 4:
+            raise ValueError("clip groups: G CUDA tensors [T,3,H,W] of one shape")
+        if isinstance(captions, (list, tuple)):
+            rows = [self._tokenise([c], clips[0].device)[0] for c in captions]
+            if len({int(r.shape[1]) for r in rows}) != 1:
+                raise ValueError("clip groups: the captions must tokenise to one length")
+            ids = torch.cat(rows, 0)
+        else:
+            ids = captions
+        if ids.dim() != 2 or ids.shape[0] != G or G * ids.shape[1] > 128:
+            raise ValueError("clip groups: token ids [G, L] with G * L <= 128")
+        size = targets[0]["size"]
+        img_h, img_w = float(size[0]), float(size[1])
+        self._ensure_packed()
+        if self._stamp[0] == "f32":
+            raise NotImplementedError("clip groups need the split-fp16 arithmetic (the weight-stream text layers)")
+        ops.range_poll(clips[0].device)
+        Tc = shp[0]
+        ids = ids.to(clips[0].device)
+        key = ("group", G, shp, tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp)
+        if not self._want_graph(key):
+            frames = torch.cat([c.to(torch.float32) for c in clips], 0)
+            out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G)
+        else:
+            ent = self._graphs.get(key)
+            if ent is None:
+                st = (torch.cat([c.to(torch.float32) for c in clips], 0), ids.clone())
+
+                def text_fn(alloc):
+                    return self._text_plan().forward(st[1], alloc)
+
+                ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, groups=G), st[0], slot)
+            if ent is None:
+                frames = torch.cat([c.to(torch.float32) for c in clips], 0)
+                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G)
+            else:  # the G clips go straight into their slices of the graph's static frame buffer (one copy launch)
+                statics = [ent[1][0][g * Tc:(g + 1) * Tc] for g in range(G)] + [ent[1][1]]
+                out = self._replay(key, (ent[0], statics) + tuple(ent[2:]), list(clips) + [ids])
+        ops.range_snapshot_async(clips[0].device)
+
+        def part(v, g):  # clip g's slice of an output of the whole group
+            if v.dim() >= 2 and v.shape[0] == 1 and v.shape[1] == G * Tc:
+                return v[:, g * Tc:(g + 1) * Tc]
+            return v[g * Tc:(g + 1) * Tc]  # memory [G*Tc, S, 256]
+
+        outs = []
+        for g in range(G):
+            o = {}
+            for k, v in out.items():
+                if torch.is_tensor(v):
+                    o[k] = part(v, g)
+                elif k == "aux_outputs":
+                    o[k] = [{kk: part(vv, g) for kk, vv in a.items()} for a in v]
+            outs.append(self._tag_diagnostics(o))
+        return outs
+
     @staticmethod
     def _tag_diagnostics(out):
         """A diagnostic launch program (TCE_ABLATE: stages skipped) marks every result it returns as garbage."""
@@ -725,13 +799,15 @@ class ReferFormer(nn.Module):
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
-    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None):
+    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None, groups=1):
         from .pipeline import run_clip
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
-            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot), valid=valid)
+            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot), valid=valid,
+                            groups=groups)
         arena, side_arena, side_stream, arena2, stream2, arena3, stream3, arena4, stream4 = res
         return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False, valid=valid,
+                        groups=groups,
                         fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
                         fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
@@ -759,7 +835,7 @@ class ReferFormer(nn.Module):
                 st[3])
 
     @torch.no_grad()
-    def hazard_check(self, frames, ids, img_hw=None, valid=None, slot=0, dry=False):
+    def hazard_check(self, frames, ids, img_hw=None, valid=None, slot=0, dry=False, groups=1):
         """Records ONE pass of the clip's launch program on the capture topology (the same arenas, side streams, forks and
         joins a captured graph is built from) and checks it for races: any two launches not ordered by a fork / join edge
         must touch disjoint memory (tce_rvos_amd/hazard.py).  frames [T,3,H,W] and token ids [1,L] on the GPU.
@@ -772,7 +848,8 @@ class ReferFormer(nn.Module):
         self._ensure_packed()
         res = self._branch_resources(frames, slot)
         st = (frames.clone(), ids.to(frames.device).clone())
-        run = lambda: self._run(st[0], lambda alloc: self._text_plan().forward(st[1], alloc), img_h, img_w, res, valid=valid)  # noqa: E731
+        run = lambda: self._run(st[0], lambda alloc: self._text_plan().forward(st[1], alloc), img_h, img_w, res, valid=valid,  # noqa: E731
+                                groups=groups)
         main = torch.cuda.Stream(device=frames.device)  # like a capture: never the legacy default stream (it syncs with all)
         main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main):

@@ -1091,12 +1091,14 @@ def xattn_pack(k, v, wqT_ext, wo, L, alloc, group=32, batch=1):
 
 
 def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_mode=RES_ADD, ln_out=None, eps_out=1e-5,
-                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256, group=32, per_batch_weights=False):
+                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256, group=32, per_batch_weights=False, w_div=1):
+    """w_div: batch entries that share one weight stream (entry b reads stream b // w_div; per_batch_weights only)."""
     from ._lib import XattnArgs
     q = XattnArgs()
     q.x, q.packed, q.bo, q.out = x.data_ptr(), pk.data_ptr(), bo.data_ptr(), out.data_ptr()
     q.M, q.batch, q.res_mode, q.eps_out, q.group = M, batch, res_mode, eps_out, group
     q.sW = pk.stride(0) if (per_batch_weights and pk.dim() == 2) else 0
+    q.w_div = max(1, int(w_div))
     q.ldx, q.ldo, q.ldres, q.lda2 = ldx, ldo, ldres, lda2
     q.sX, q.sRes, q.sOut = sX, sRes, sOut
     if a2 is not None:

@@ -109,15 +109,15 @@ class _Fork:
 
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-             fork3=None, valid=None):
+             fork3=None, valid=None, groups=1):
     """The clip's launch program with the model's own packed-weight routes active (ops.Routes).  valid = (rows, columns) of
     the frames that are not padding (None: un-padded clip)."""
     with ops.routes(model._routes):
-        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid)
+        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid, groups)
 
 
 def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-              fork3=None, valid=None):
+              fork3=None, valid=None, groups=1):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
@@ -128,7 +128,17 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     fork3 = ((arena, stream), (arena, stream)): two more for its stride-32 / stride-16 lateral paths (_pixel_decoder)."""
     cfg, w = model.cfg, model._packed
     dev = frames.device
+    # Clip groups (groups = G > 1): `frames` holds G independent clips of Tc frames each, back to back.  Every per-frame /
+    # per-token stage simply sees T = G * Tc frames (more rows per launch: the latency-bound stages -- Swin stages 3-4, the text
+    # branch, the token and decoder paths -- are shared by the G clips); the stages that look ACROSS a clip's frames or at its
+    # caption are block-diagonal per clip: the frame tokens' self-attention, the IQT self-attention, the VisionLanguageBlocks'
+    # self-attention, every text cross-attention (one folded weight stream per clip), the decoder's start from the clip's
+    # sentence feature.  Each clip's result is the B = 1 forward's (the reference MIXES the clips of a batch, SURVEY 8e).
+    G = int(groups)
     T, _, H0, W0 = frames.shape
+    if T % G:
+        raise ValueError("clip group: frames must hold `groups` clips of equal length")
+    Tc = T // G
     ar.reset()
     if side_arena is not None:
         side_arena.reset()
@@ -174,43 +184,47 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 text_hidden, text_pooled = tA(32, cfg.text_hidden), tA(cfg.text_hidden)
             else:
                 text_hidden, text_pooled = text_in(tA) if callable(text_in) else text_in
-            L = text_hidden.shape[0]
+            GL = text_hidden.shape[0]  # G captions of L tokens, caption-major
+            if GL % G:
+                raise ValueError("clip group: the text features must hold `groups` captions of equal length")
+            L = GL // G
             TH = cfg.text_hidden
-            if text_pooled.data_ptr() == text_hidden.data_ptr() + L * TH * 4 and text_hidden.is_contiguous():
-                # the text plan hands hidden states and pooled vector over as one [L + 1, 768] tensor: one resizer launch pair
-                tmp = _lin(tA, text_hidden, L + 1, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-                both = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L + 1, D))
-                text, sent = both[:L], both[L:]
+            if text_pooled.data_ptr() == text_hidden.data_ptr() + GL * TH * 4 and text_hidden.is_contiguous():
+                # the text plan hands hidden states and pooled vectors over as one [G*L + G, 768] tensor: one resizer launch pair
+                tmp = _lin(tA, text_hidden, GL + G, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                both = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(GL + G, D))
+                text, sent = both[:GL], both[GL:]
             else:
-                tmp = _lin(tA, text_hidden, L, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-                text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(L, D))
-                tmp = _lin(tA, text_pooled, 1, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
-                sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(1, D))
+                tmp = _lin(tA, text_hidden, GL, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                text = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(GL, D))
+                tmp = _lin(tA, text_pooled, G, TH, w["resizer.fc.weight"], w["resizer.fc.bias"], D)
+                sent = ops.layernorm(tmp, w["resizer.layer_norm.weight"], w["resizer.layer_norm.bias"], 1e-12, out=tA(G, D))
             text_pos = model._text_pos(L, dev)
             xattn_ok = L <= 32 and ops.get_gemm_mode() != "f32"
 
             def text_site(pre, rows, group):
                 """(k, v, folded stream or None) of the cross-attention module `pre` whose largest launch has `rows` rows.
                 The folded stream is packed in the arithmetic of the site group that consumes it."""
-                k = tA(L, D)
-                if few(L, "text"):  # key (text + position) and value projections of the site in one launch
-                    v = tA(L, D)
-                    FR(text, L, D, [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, 0), (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, 0)],
-                       a2=text_pos, lda2=D)
+                k = tA(GL, D)  # [G][L, D]: every caption's keys (the position map is shared by the captions)
+                if few(GL, "text"):  # key (text + position) and value projections of the site in one launch
+                    v = tA(GL, D)
+                    FR(text, GL, D, [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, 0), (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, 0)],
+                       a2=text_pos, lda2=D, a2_rows=L)
                 else:
-                    gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D)
-                    v = _lin(tA, text, L, D, w[pre + "v.w"], w[pre + "v.b"], D)
+                    gemm_ex(text, w[pre + "k.w"], k, L, D, D, D, D, D, bias=w[pre + "k.b"], a2=text_pos, lda2=D, batch=G, sA=L * D,
+                            sA2=0, sC=L * D)
+                    v = _lin(tA, text, GL, D, w[pre + "v.w"], w[pre + "v.b"], D)
                 pk = None
                 if xattn_ok and rows >= ops.XATTN_MIN_ROWS:
-                    with model.arith(group):
-                        pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA)
+                    with model.arith(group):  # one folded weight stream per caption
+                        pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], L, tA, batch=G)
                 return k, v, pk
 
-            fk, fv, fpk = text_site("fusion_module.multihead_attn.", T * lvl_sizes[0][0] * lvl_sizes[0][1], "input_proj")
+            fk, fv, fpk = text_site("fusion_module.multihead_attn.", Tc * lvl_sizes[0][0] * lvl_sizes[0][1], "input_proj")
             if cfg.vlblock:
                 for stage in (4, 3, 2, 1):
                     h_, w_ = sizes[stage - 1]
-                    vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", T * h_ * w_, "pixel.xattn")
+                    vl_sites[stage] = text_site(f"pixel_decoder.cross_attn_{stage}.multihead_attn.", Tc * h_ * w_, "pixel.xattn")
 
 
     # Capture order = submission order of a replay (the graph's nodes are enqueued in the order they were captured): the ~140
@@ -279,14 +293,14 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                                       ws=A(sk * T * h * ww * D) if sk > 1 else None)
             assert (ho, wo) == (h, ww)
         s = ops.groupnorm_cl(s, w[f"input_proj.{l}.1.weight"], w[f"input_proj.{l}.1.bias"], T, hw, D, 32, alloc=A)
-        if fpk is not None and T * hw >= ops.XATTN_MIN_ROWS:
-            # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]
+        if fpk is not None and Tc * hw >= ops.XATTN_MIN_ROWS:
+            # src_l = s * MHA(s, text): straight into the level slice of [T, S, 256]; the Tc frames of a clip share its stream
             ops.xattn_fused(s, fpk, w["fusion_module.multihead_attn.out_proj.bias"], hw, src[starts[l]:], res_mode=RES_MUL,
-                            batch=T, sX=hw * D, sRes=hw * D, sOut=S * D)
+                            batch=T, sX=hw * D, sRes=hw * D, sOut=S * D, per_batch_weights=G > 1, w_div=Tc)
         else:
             q = _lin(A, s, T * hw, D, w["fusion_module.multihead_attn.q.w"], w["fusion_module.multihead_attn.q.b"], D)
             att = A(T * hw, D)
-            ops.mha_core(q, fk, fv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            ops.mha_core(q, fk, fv, G, NH, Tc * hw, L, D, D, D, Tc * hw * D, L * D, L * D, att, D, Tc * hw * D)
             # src_l = s * out_proj(att), written straight into the level slice of [T, S, 256]
             gemm_ex(att, w["fusion_module.multihead_attn.out_proj.weight"], src[starts[l]:], hw, D, D, D, D, D,
                     bias=w["fusion_module.multihead_attn.out_proj.bias"], res=s, ldres=D, res_mode=RES_MUL, batch=T,
@@ -313,7 +327,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         with model.arith("backbone.merge"):  # a ResNet is convolutions only: one site group
             feats = _resnet_backbone(model, frames, ar, sizes)
     else:
-        feats = _swin_backbone(model, frames, ar, sizes, on_stage)
+        feats = _swin_backbone(model, frames, ar, sizes, on_stage, G)
 
     _stage("backbone")
     text_fork.join()
@@ -327,7 +341,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         ar2.reset()
         lat1_fork = _Fork(stream2)
         with lat1_fork:
-            return (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2))
+            return (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2, G))
     # When it starts is a trade: its long kernels (72000-row cross-attention, FFN, GEMMs) slow down whatever runs beside
     # them, and it must be done when the chain reaches stride 4.  Measured at config 2 (ms per clip): right after Swin
     # stage 0 8.09, after the backbone 7.44, after encoder layer 0 / 1 / 2 / 3 (of 4) 7.41 / 7.37 / 7.27 / 7.71 ->
@@ -479,7 +493,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     att = A(R, D)
                     tap(f"L{i}.qk2", qk)
                     tap(f"L{i}.v2", v)
-                    ops.mha_core(qk, qk[:, D:], v, 1, NH, R, R, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0)
+                    Rc = Tc * Fk  # a clip's tokens attend to each other (:463-469), never to another clip's
+                    ops.mha_core(qk, qk[:, D:], v, G, NH, Rc, Rc, 2 * D, 2 * D, D, Rc * 2 * D, Rc * 2 * D, Rc * D, att, D, Rc * D)
                     tap(f"L{i}.att2", att)
                     if few(R, "ftf2"):
                         FR(att, R, D, [(w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], token, D, D, False, ops.FR_NONE)],
@@ -557,7 +572,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             r = _lin(A, qpos, Q, D, w["transformer.reference_points.weight"], w["transformer.reference_points.bias"], 2)
             r = ops.sigmoid(r, out=A(Q, 2))
         init_ref = ops.tile(r, T, out=A(T * Q, 2))
-        tgt = ops.tile(sent, T * Q, out=A(T * Q, D))
+        tgt = A(T * Q, D)  # every (frame, query) of a clip starts from the clip's sentence feature
+        for g_ in range(G):
+            ops.tile(sent[g_], Tc * Q, out=tgt[g_ * Tc * Q:(g_ + 1) * Tc * Q])
         ref, ref_dim = init_ref, 2
         for lid in range(0 if "decoder" not in ABLATE else nl, nl):
             lp = f"transformer.decoder.layers.{lid}."
@@ -577,8 +594,11 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 v = _lin(A, prev, T * Q, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(T * Q, D)
             if cfg.qtrans:
-                # IQT (:683): [T, Q, C] fed seq-first: sequence axis = frames, batch axis = query slots
-                ops.mha_core(qk, qk[:, D:], v, Q, NH, T, T, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att, Q * D, D)
+                # IQT (:683): [T, Q, C] fed seq-first: sequence axis = the clip's frames, batch axis = query slots
+                for g_ in range(G):
+                    r0 = g_ * Tc * Q
+                    ops.mha_core(qk[r0:], qk[r0:, D:], v[r0:], Q, NH, Tc, Tc, Q * 2 * D, Q * 2 * D, Q * D, 2 * D, 2 * D, D, att[r0:],
+                                 Q * D, D)
             else:
                 ops.mha_core(qk, qk[:, D:], v, T, NH, Q, Q, 2 * D, 2 * D, D, Q * 2 * D, Q * 2 * D, Q * D, att, D, Q * D)
             if few(T * Q, "dec"):
@@ -661,7 +681,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
-    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1, par=fork3)
+    mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1, par=fork3, G=G)
     dec_fork.join()
 
     _stage("pixel decoder")
@@ -696,10 +716,12 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     return out
 
 
-def _swin_backbone(model, frames, ar, sizes, on_stage=None):
+def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1):
     """swin_transformer.py:595-617: returns the four normed stage maps, token-major [T*h*w, C_i].
     Video-Swin (video_swin_transformer.py:678-697): same program with the 3-D window kernel, the (1,4,4) patch
-    conv applied per frame, stage outputs taken before the merge and WITHOUT an output norm."""
+    conv applied per frame, stage outputs taken before the merge and WITHOUT an output norm.
+    G > 1 (a clip group): the 2-D windows never leave a frame, so the G clips are simply more frames; the 3-D windows span a
+    clip's frames, so the 3-D window kernel is launched once per clip on that clip's rows."""
     cfg, w = model.cfg, model._packed
     A = ar.alloc
     T = frames.shape[0]
@@ -746,8 +768,12 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None):
                         ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], out=xn)
                         gemm_ex(xn, w[p + "attn.qkv.weight"], qkv, ntok, 3 * C, C, C, C, 3 * C, bias=w[p + "attn.qkv.bias"])
                     if cfg.video:
-                        att = ops.window_attn3d(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H,
-                                                W, C, nH, j % 2 == 1, out=xn)
+                        nc = ntok // G
+                        for g_ in range(G):
+                            ops.window_attn3d(qkv[g_ * nc:(g_ + 1) * nc], w[p + "attn.qkv.bias"],
+                                              w[p + "attn.relative_position_bias_table"], T // G, H, W, C, nH, j % 2 == 1,
+                                              out=xn[g_ * nc:(g_ + 1) * nc])
+                        att = xn
                     else:
                         att = ops.window_attn(qkv, w[p + "attn.qkv.bias"], w[p + "attn.relative_position_bias_table"], T, H, W,
                                               C, nH, 0 if j % 2 == 0 else cfg.window_size // 2, out=xn)
@@ -833,7 +859,7 @@ def _resnet_backbone(model, frames, ar, sizes):
     return feats
 
 
-def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
+def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1):
     """Lateral branch of one FPN level (segmentation.py:187-196,326-377): 1x1 adapter + GroupNorm(8) + VisionLanguageBlock.
     Returns tgt [T*hw, 256] allocated in `arx` (temporaries released, tgt stays).  Stage 1 reads the backbone map
     (memory may be None), stages 2-4 the encoder memory."""
@@ -874,7 +900,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                     lda2=D, batch=T, sA=nh_ * nw_ * D, sA2=0, sC=nh_ * nw_ * 2 * D)
             v = _lin(A, x_low, n_low, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(n_low, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n_low, n_low, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A,
+            nc = n_low // G  # a clip's reduced tokens attend to each other only
+            ops.mha_core(qk, qk[:, D:], v, G, NH, nc, nc, 2 * D, 2 * D, D, nc * 2 * D, nc * 2 * D, nc * D, att, D, nc * D, alloc=A,
                          kmask=sc["kmask"].get(stage))  # padded clips: padded positions are no keys (segmentation.py:345-356)
             o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
             ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
@@ -885,7 +912,9 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
                     batch=T, sA=hw * D, sA2=0, sC=hw * 2 * D)
             v = _lin(A, tgt, n, D, w[pre + "v.w"], w[pre + "v.b"], D)
             att = A(n, D)
-            ops.mha_core(qk, qk[:, D:], v, 1, NH, n, n, 2 * D, 2 * D, D, 0, 0, 0, att, D, 0, alloc=A, kmask=sc["kmask"].get(stage))
+            nc = n // G
+            ops.mha_core(qk, qk[:, D:], v, G, NH, nc, nc, 2 * D, 2 * D, D, nc * 2 * D, nc * 2 * D, nc * D, att, D, nc * D, alloc=A,
+                         kmask=sc["kmask"].get(stage))
             gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                     ldres=D, res_mode=RES_ADD)
         arx.release(m1)
@@ -895,16 +924,19 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
     with model.arith("pixel.xattn"):
         m1 = arx.mark()
         tk, tv, pk = vl_sites[stage]
+        Mc = (T // G) * hw  # rows of one clip
         if pk is not None:
-            # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch
-            ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], T * hw, tgt, a2=pos, a2_rows=hw,
-                            ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]))
+            # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch (one batch entry
+            # and one folded weight stream per clip)
+            ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], Mc, tgt, a2=pos, a2_rows=hw,
+                            ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]), batch=G, sX=Mc * D, sOut=Mc * D,
+                            per_batch_weights=G > 1)
         else:
             q = A(T * hw, D)
             gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
                     sA2=0, sC=hw * D)
             att = A(T * hw, D)
-            ops.mha_core(q, tk, tv, 1, NH, T * hw, L, D, D, D, 0, 0, 0, att, D, 0)
+            ops.mha_core(q, tk, tv, G, NH, Mc, L, D, D, D, Mc * D, L * D, L * D, att, D, Mc * D)
             _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
                          w[bp + "norm2.bias"])
         arx.release(m1)
@@ -913,7 +945,7 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx):
 
 
 
-def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=None, par=None):
+def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=None, par=None, G=1):
     """CrossModalFPNDecoder.forward: top-down FPN with a VisionLanguageBlock at every level.
 
     The lateral branch of a level (_lateral) depends only on its input map and the text; only the top-down merge + 3x3
@@ -945,19 +977,19 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
         ar4.reset()
         fk_l3 = _Fork(st4)
         with fk_l3:
-            tgt3 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 3, ar4)
+            tgt3 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 3, ar4, G)
         fk_c = _Fork(st3)
         with fk_c:
             (h4, w4), (h3, w3) = sizes[3], sizes[2]
             y4, y3 = ar3.alloc(T * h4 * w4, D), ar3.alloc(T * h3 * w3, D)
-            tgt4 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 4, ar3)
+            tgt4 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 4, ar3, G)
             merge_conv(tgt4, 4, None, None, ar3, y4)
             fk_l3.join()  # this branch waits for the stride-16 lateral
             merge_conv(tgt3, 3, y4, (h4, w4), ar3, y3)
         h, ww = sizes[1]
         y2 = A(T * h * ww, D)
         m0 = ar.mark()
-        tgt2 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 2, ar)
+        tgt2 = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, 2, ar, G)
         fk_c.join()
         merge_conv(tgt2, 2, y3, (h3, w3), ar, y2)
         ar.release(m0)
@@ -972,7 +1004,7 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
             lat1[0].join()
             tgt = lat1[1]
         else:
-            tgt = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, ar)
+            tgt = _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, ar, G)
         merge_conv(tgt, stage, y, y_hw, ar, y_new)
         ar.release(m0)
         y, y_hw = y_new, (h, ww)

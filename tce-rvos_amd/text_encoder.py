@@ -38,19 +38,25 @@ class TextPlan:
             self.layers.append((wqkv, bqkv, p))
 
     def forward(self, ids, A):
-        """ids int64 [1, L] on the GPU; A = arena allocator.  Returns (last_hidden_state [L,C], pooler_output [C]).
+        """ids int64 [G, L] on the GPU (G captions of equal length: one per clip of a clip group; G = 1 for a single clip);
+        A = arena allocator.  Returns (last_hidden_state [G*L, C] caption-major, pooler_output [C] for G = 1, [G, C] otherwise);
+        the two live in ONE [G*L + G, C] buffer, so the resizer takes them as one tensor (pipeline.text_stage).
         (The few-row kernel of csrc/fewrow.hip was tried for the dense layers and is slower at K = 768 / 3072 than the
         split-K GEMM: 12.7 vs 9.8 us, profiles/r03_fewrow.txt.)"""
-        sd, C, L = self.sd, self.C, ids.shape[1]
+        sd, C = self.sd, self.C
+        G, Ls = int(ids.shape[0]), int(ids.shape[1])
+        L = G * Ls  # rows of every activation below
         s = ops._stream()
-        xbuf = A(L + 1, C)  # row L receives the pooler output: hidden states and pooled vector are ONE [L + 1, C] tensor for the
-        x = xbuf[:L]         # resizer (one projection + one LayerNorm launch for both, pipeline.text_stage)
+        xbuf = A(L + G, C)  # rows L.. receive the pooler outputs
+        x = xbuf[:L]
         # position ids (HF create_position_ids_from_input_ids) are derived inside the kernel: no ATen arithmetic here
-        check(lib().tce_embed_ln_f32(ids.data_ptr(), None, sd["embeddings.word_embeddings.weight"].data_ptr(),
-                                     sd["embeddings.position_embeddings.weight"].data_ptr(),
-                                     sd["embeddings.token_type_embeddings.weight"].data_ptr(),
-                                     sd["embeddings.LayerNorm.weight"].data_ptr(), sd["embeddings.LayerNorm.bias"].data_ptr(),
-                                     x.data_ptr(), L, C, self.eps, self.pad, s), "tce_embed_ln_f32")
+        emb = (sd["embeddings.word_embeddings.weight"].data_ptr(), sd["embeddings.position_embeddings.weight"].data_ptr(),
+               sd["embeddings.token_type_embeddings.weight"].data_ptr(), sd["embeddings.LayerNorm.weight"].data_ptr(),
+               sd["embeddings.LayerNorm.bias"].data_ptr())
+        if G == 1:
+            check(lib().tce_embed_ln_f32(ids.data_ptr(), None, *emb, x.data_ptr(), L, C, self.eps, self.pad, s), "tce_embed_ln_f32")
+        else:
+            check(lib().tce_embed_ln_seqs_f32(ids.data_ptr(), *emb, x.data_ptr(), G, Ls, C, self.eps, self.pad, s), "tce_embed_ln_seqs_f32")
         qkv, att, hdn = A(L, 3 * C), A(L, C), A(L, self.ff)
         # M = L (32 tokens) against 768..3072-deep weights: split K so that ~200 workgroups stream each weight matrix
         # instead of N/64 (ops.splitk_for); the partial sums meet in `ws`
@@ -65,8 +71,8 @@ class TextPlan:
             ws_b = A(max(t_out * L * C, t_f2 * L * C))             # out-proj planes / fc2 planes
             for wqkv, bqkv, p in self.layers:
                 ops.thin_partials(x, wqkv, ws_a, L, 3 * C, C)
-                check(lib().tce_mha_small64_splits_f32(ws_a.data_ptr(), t_qkv, bqkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s),
-                      "tce_mha_small64_splits_f32")
+                check(lib().tce_mha_small64_seqs_f32(ws_a.data_ptr(), t_qkv, bqkv.data_ptr(), att.data_ptr(), G, Ls, self.heads, 0.125, s),
+                      "tce_mha_small64_seqs_f32")
                 ops.thin_partials(att, sd[p + "attention.output.dense.weight"], ws_b, L, C, C)
                 ops.splitk_reduce(ws_b, t_out, L, C, x, bias=sd[p + "attention.output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
                                   ln=(sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"]), eps=self.eps)
@@ -75,7 +81,10 @@ class TextPlan:
                                   bias_x=sd[p + "intermediate.dense.bias"], act_x=ACT_GELU)
                 ops.splitk_reduce(ws_b, t_f2, L, C, x, bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
                                   ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]), eps=self.eps)
-            return self._pooler(x, xbuf[L], s)
+            return self._pooler(x, xbuf, G, Ls, s)
+        if G > 1:
+            raise NotImplementedError("several captions per forward (clip groups) need the split-fp16 arithmetic and G * L <= 128 "
+                                      "tokens (the weight-stream text layers, csrc/thin.hip)")
         ws = A(max(sk_qkv * L * 3 * C, sk_out * L * C, sk_f1 * L * self.ff, sk_f2 * L * C))
         for wqkv, bqkv, p in self.layers:
             gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
@@ -89,10 +98,12 @@ class TextPlan:
             gemm_ex(hdn, sd[p + "output.dense.weight"], x, L, C, self.ff, self.ff, self.ff, C,
                     bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD, splitk=sk_f2, ws=ws, ln_eps=self.eps,
                     ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]))
-        return self._pooler(x, xbuf[L], s)
+        return self._pooler(x, xbuf, G, Ls, s)
 
-    def _pooler(self, x, pooled, s):
+    def _pooler(self, x, xbuf, G, Ls, s):
+        """pooler_output = tanh(dense(first token of each caption)) -> rows G*Ls .. of xbuf"""
         sd, C = self.sd, self.C
-        gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"])
-        check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), C, s), "tce_tanh_f32")
-        return x, pooled
+        pooled = xbuf[G * Ls:]
+        gemm_ex(x, sd["pooler.dense.weight"], pooled, 1, C, C, C, C, C, bias=sd["pooler.dense.bias"], batch=G, sA=Ls * C, sC=C)
+        check(lib().tce_tanh_f32(pooled.data_ptr(), pooled.data_ptr(), G * C, s), "tce_tanh_f32")
+        return x, (pooled[0] if G == 1 else pooled)

@@ -923,3 +923,88 @@ def test_hazard_checker_sees_a_dropped_join(models, monkeypatch):
     torch.cuda.synchronize()
     print(rep)
     assert not rep.clean and rep.n_conflicts > 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Clip groups: G independent clips as ONE launch program (model.forward_group)
+# ---------------------------------------------------------------------------------------------------------------------
+def _group_inputs(G, T, H, W, L, seed=70):
+    clips = [synth_frames(T, H, W, seed + i).cuda() for i in range(G)]
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 50000, (G, L), generator=g).cuda()  # G different captions of one length
+    return clips, ids
+
+
+GROUP_KEYS = ("pred_logits", "pred_boxes", "pred_masks", "memory", "reference_points")
+
+
+@pytest.mark.parametrize("backbone,G,T,H,W,L", [("swin_t_p4w7", 2, 3, 96, 132, 9),      # small: the un-fused forms
+                                                ("swin_t_p4w7", 3, 2, 64, 96, 40),      # > 32 tokens: un-folded text cross-attention
+                                                ("swin_t_p4w7", 2, 5, 360, 640, 32),    # BASELINE config 2 shapes
+                                                ("swin_t_p4w7", 4, 5, 360, 640, 32),
+                                                ("video_swin_t_p4w7", 2, 4, 96, 128, 9),  # 3-D windows: one launch per clip
+                                                ("resnet50", 3, 1, 96, 128, 9)])
+def test_clip_group_matches_one_clip_at_a_time(models, backbone, G, T, H, W, L):
+    """A group of G clips is block-diagonal across clips at every stage that looks across frames or at the caption, so each
+    clip's outputs are its B = 1 forward's: same arithmetic per row, but some sites take another kernel route at the group's
+    row count (a different summation order) -- hence a tolerance, 2e-5 of the tensor's range, not bit equality.  Eager pass,
+    capture and replay of the group must agree bit for bit with each other."""
+    model = models(backbone, 31)
+    clips, ids = _group_inputs(G, T, H, W, L)
+    tgt = [{"size": torch.tensor([H, W])}]
+    solo = [model([clips[g]], ids[g:g + 1], tgt) for g in range(G)]
+    solo = [{k: v.clone() for k, v in o.items() if k in GROUP_KEYS} for o in solo]
+    runs = []
+    for _ in range(3):  # eager, capture, replay
+        outs = model.forward_group(clips, ids, tgt)
+        torch.cuda.synchronize()
+        runs.append([{k: o[k].clone() for k in GROUP_KEYS if k in o} for o in outs])
+    assert len(runs[0]) == G
+    for g in range(G):
+        for k in solo[g]:
+            ref, got = solo[g][k], runs[0][g][k]
+            assert got.shape == ref.shape, (g, k, got.shape, ref.shape)
+            tol = 2e-5 * float(ref.abs().max()) + 1e-6
+            err = float((got - ref).abs().max())
+            assert err <= tol, (g, k, err, tol)
+            for r in runs[1:]:
+                assert torch.equal(r[g][k], got), (g, k, "replay != eager")
+        m_ref, m_got = solo[g]["pred_masks"] > 0, runs[0][g]["pred_masks"] > 0
+        inter, union = (m_ref & m_got).sum().item(), (m_ref | m_got).sum().item()
+        assert union == 0 or inter / union > 0.9999
+
+
+def test_clip_group_clips_do_not_see_each_other(models):
+    """Changing clip 1 (frames and caption) must leave clip 0's outputs bit-identical: nothing crosses the clips of a group."""
+    model = models("swin_t_p4w7", 31)
+    H, W = 96, 132
+    tgt = [{"size": torch.tensor([H, W])}]
+    clips, ids = _group_inputs(2, 3, H, W, 9)
+    a = model.forward_group(clips, ids, tgt)[0]
+    a = {k: a[k].clone() for k in GROUP_KEYS}
+    other, ids2 = _group_inputs(2, 3, H, W, 9, seed=123)
+    ids_b = torch.cat([ids[:1], ids2[1:]], 0)
+    b = model.forward_group([clips[0], other[1]], ids_b, tgt)[0]
+    for k in GROUP_KEYS:
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("backbone,G,T,H,W", [("swin_t_p4w7", 2, 3, 96, 132), ("swin_t_p4w7", 4, 5, 360, 640),
+                                              ("video_swin_t_p4w7", 2, 8, 384, 640)])
+def test_clip_group_launch_program_is_race_free(models, backbone, G, T, H, W):
+    model = models(backbone, 5)
+    clips, ids = _group_inputs(G, T, H, W, 32)
+    rep = model.hazard_check(torch.cat(clips, 0), ids, (H, W), groups=G)
+    print(rep)
+    assert rep.launches > 200 and rep.unordered_pairs > 1000
+    assert rep.clean, str(rep)
+
+
+def test_clip_group_rejects_ragged_groups(models):
+    model = models("swin_t_p4w7", 31)
+    tgt = [{"size": torch.tensor([96, 128])}]
+    clips, ids = _group_inputs(2, 3, 96, 128, 9)
+    with pytest.raises(ValueError):
+        model.forward_group([clips[0], clips[1][:2]], ids, tgt)
+    with pytest.raises(ValueError):
+        model.forward_group(clips, ids[:1], tgt)
