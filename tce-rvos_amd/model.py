@@ -631,7 +631,8 @@ class ReferFormer(nn.Module):
         batch dimension, which mixes the clips of a batch.  Why: a clip alone leaves the GPU latency-bound for a third
         of its time (Swin stages 3-4 at 4600 rows, the text branch, the token / decoder paths); G clips share those launches:
         DESIGN section 3.10 has the measured clips/s.  Video-Swin's 3-D windows span a clip's frames: its window kernel is launched
-        per clip, everything else is shared.  Limits: un-padded clips, G * L <= 128 caption tokens, the split-fp16 arithmetic."""
+        per clip, everything else is shared.  Limits: one clip shape and one caption length per group, un-padded clips, G <= 64 (the
+        text layers leave the weight-stream kernels for the tiled GEMMs above 128 caption tokens in all)."""
         G = len(clips)
         if G == 1:
             cap = captions[:1] if torch.is_tensor(captions) else [captions[0]]
@@ -646,13 +647,11 @@ class ReferFormer(nn.Module):
             ids = torch.cat(rows, 0)
         else:
             ids = captions
-        if ids.dim() != 2 or ids.shape[0] != G or G * ids.shape[1] > 128:
-            raise ValueError("clip groups: token ids [G, L] with G * L <= 128")
+        if ids.dim() != 2 or ids.shape[0] != G or G > 64:
+            raise ValueError("clip groups: token ids [G, L], G <= 64")
         size = targets[0]["size"]
         img_h, img_w = float(size[0]), float(size[1])
         self._ensure_packed()
-        if self._stamp[0] == "f32":
-            raise NotImplementedError("clip groups need the split-fp16 arithmetic (the weight-stream text layers)")
         ops.range_poll(clips[0].device)
         Tc = shp[0]
         ids = ids.to(clips[0].device)

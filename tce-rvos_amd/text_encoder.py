@@ -82,13 +82,15 @@ class TextPlan:
                 ops.splitk_reduce(ws_b, t_f2, L, C, x, bias=sd[p + "output.dense.bias"], res=x, ldres=C, res_mode=RES_ADD,
                                   ln=(sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]), eps=self.eps)
             return self._pooler(x, xbuf, G, Ls, s)
-        if G > 1:
-            raise NotImplementedError("several captions per forward (clip groups) need the split-fp16 arithmetic and G * L <= 128 "
-                                      "tokens (the weight-stream text layers, csrc/thin.hip)")
+        # (more than 128 rows -- a large clip group -- or the exact-fp32 arithmetic: tiled GEMMs; attention per caption as above)
         ws = A(max(sk_qkv * L * 3 * C, sk_out * L * C, sk_f1 * L * self.ff, sk_f2 * L * C))
         for wqkv, bqkv, p in self.layers:
             gemm_ex(x, wqkv, qkv, L, 3 * C, C, C, C, 3 * C, bias=bqkv, splitk=sk_qkv, ws=ws)
-            check(lib().tce_mha_small64_f32(qkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s), "tce_mha_small64_f32")
+            if G == 1:
+                check(lib().tce_mha_small64_f32(qkv.data_ptr(), att.data_ptr(), L, self.heads, 0.125, s), "tce_mha_small64_f32")
+            else:
+                check(lib().tce_mha_small64_seqs_f32(qkv.data_ptr(), 1, None, att.data_ptr(), G, Ls, self.heads, 0.125, s),
+                      "tce_mha_small64_seqs_f32")
             # dense + residual + LayerNorm: the norm rides in the split-K reduction pass
             gemm_ex(att, sd[p + "attention.output.dense.weight"], x, L, C, C, C, C, C, bias=sd[p + "attention.output.dense.bias"],
                     res=x, ldres=C, res_mode=RES_ADD, splitk=sk_out, ws=ws, ln_eps=self.eps,

@@ -943,7 +943,9 @@ GROUP_KEYS = ("pred_logits", "pred_boxes", "pred_masks", "memory", "reference_po
                                                 ("swin_t_p4w7", 2, 5, 360, 640, 32),    # BASELINE config 2 shapes
                                                 ("swin_t_p4w7", 4, 5, 360, 640, 32),
                                                 ("video_swin_t_p4w7", 2, 4, 96, 128, 9),  # 3-D windows: one launch per clip
-                                                ("resnet50", 3, 1, 96, 128, 9)])
+                                                ("resnet50", 3, 1, 96, 128, 9),
+                                                ("resnet50", 8, 1, 96, 128, 20),        # 160 caption tokens: tiled-GEMM text layers
+                                                ("swin_t_p4w7", 5, 2, 64, 96, 33)])
 def test_clip_group_matches_one_clip_at_a_time(models, backbone, G, T, H, W, L):
     """A group of G clips is block-diagonal across clips at every stage that looks across frames or at the caption, so each
     clip's outputs are its B = 1 forward's: same arithmetic per row, but some sites take another kernel route at the group's
