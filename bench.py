@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--group", type=int, default=1,
                     help="clips per forward as ONE launch program (model.forward_group): independent clips, block-diagonal across "
                          "clips, each clip's result = its B=1 forward's; the latency-bound stages are shared by the group")
+    ap.add_argument("--same-clip", action="store_true",
+                    help="with --group G: the G forwards of a group are G captions on ONE clip (the expressions of a video): the "
+                         "backbone runs once per group; `value` then counts (clip, expression) pairs per second")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1 without the per-step mask all-gather (barrier + max-over-ranks timing only): isolates the "
                          "compute side of a ranks-per-GPU measurement from gloo's host-side copies")
@@ -191,6 +194,8 @@ def main():
         """the forward(s) of one unit of a step: a list of per-clip output dicts (Gp of them for a clip group)"""
         if Gp > 1:
             k = (i * Gp) % n_pool
+            if args.same_clip:
+                return model.forward_group([clips[k]] * Gp, ids_groups[k], targets, slot=slot)
             return model.forward_group([clips[(k + j) % n_pool] for j in range(Gp)], ids_groups[k], targets, slot=slot)
         tok = ids_host[i % n_pool] if use_host_ids else ids[i % n_pool]
         return [model([clips[i % n_pool]], tok, targets, slot=slot)]
@@ -433,7 +438,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"{args.backbone} T={T} {H}x{W} + {args.tokens}-token text, B=1 clip per forward, "
                                        f"flags --with_box_refine --binary --f_token 8 --qtrans ({cfg_name})",
-                           "clips_per_step": world * C * Gp, "clips_in_flight_per_gpu": C, "clips_per_forward": Gp,
+                           "clips_per_step": world * C * Gp, "clips_in_flight_per_gpu": C, "clips_per_forward": Gp, "same_clip_in_group": bool(args.same_clip and Gp > 1),
                            "ranks_per_gpu": args.ranks_per_gpu,
                            "parallelism": f"clip-sharded x{world}" +
                                           ((" + harness kernel + " + ("RCCL" if args.backend == "nccl" else "gloo") +

@@ -7,6 +7,7 @@ that launches hand-written HIP kernels (libtce_rvos.so) on token-major / channel
 a bump arena.  PyTorch supplies device memory, the stream and the (third-party) RoBERTa text encoder.
 """
 import os
+import types
 import math
 from collections import OrderedDict
 from typing import List, Optional
@@ -631,7 +632,8 @@ class ReferFormer(nn.Module):
         batch dimension, which mixes the clips of a batch.  Why: a clip alone leaves the GPU latency-bound for a third
         of its time (Swin stages 3-4 at 4600 rows, the text branch, the token / decoder paths); G clips share those launches:
         DESIGN section 3.10 has the measured clips/s.  Video-Swin's 3-D windows span a clip's frames: its window kernel is launched
-        per clip, everything else is shared.  Limits: one clip shape and one caption length per group, un-padded clips, G <= 64 (the
+        per clip, everything else is shared.  When `clips` holds the SAME tensor G times (G expressions of one video, the inner loop
+        of inference_ytvos.py) the backbone runs once for the group.  Limits: one clip shape and one caption length per group, un-padded clips, G <= 64 (the
         text layers leave the weight-stream kernels for the tiled GEMMs above 128 caption tokens in all)."""
         G = len(clips)
         if G == 1:
@@ -654,26 +656,38 @@ class ReferFormer(nn.Module):
         self._ensure_packed()
         ops.range_poll(clips[0].device)
         Tc = shp[0]
-        ids = ids.to(clips[0].device)
-        key = ("group", G, shp, tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp)
+        dev = clips[0].device
+        ids = ids.to(dev)
+        # one clip, G captions (the expressions of a video: the SAME tensor G times): the backbone runs once
+        shared = all(c is clips[0] for c in clips[1:])
+        srcs = [clips[0]] if shared else list(clips)
+        key = ("group", G, shared, shp, tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp)
+
+        def frames_now():
+            return srcs[0].to(torch.float32).contiguous() if shared else torch.cat([c.to(torch.float32) for c in srcs], 0)
+
+        def eager():
+            return self._run(frames_now(), lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G,
+                             shared=shared)
+
         if not self._want_graph(key):
-            frames = torch.cat([c.to(torch.float32) for c in clips], 0)
-            out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G)
+            out = eager()
         else:
             ent = self._graphs.get(key)
             if ent is None:
-                st = (torch.cat([c.to(torch.float32) for c in clips], 0), ids.clone())
+                st = (frames_now().clone() if shared else frames_now(), ids.clone())
 
                 def text_fn(alloc):
                     return self._text_plan().forward(st[1], alloc)
 
-                ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, groups=G), st[0], slot)
+                like = types.SimpleNamespace(shape=(G * Tc,) + shp[1:], device=dev)  # arenas are sized for the whole group
+                ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, groups=G, shared=shared), like, slot)
             if ent is None:
-                frames = torch.cat([c.to(torch.float32) for c in clips], 0)
-                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G)
-            else:  # the G clips go straight into their slices of the graph's static frame buffer (one copy launch)
-                statics = [ent[1][0][g * Tc:(g + 1) * Tc] for g in range(G)] + [ent[1][1]]
-                out = self._replay(key, (ent[0], statics) + tuple(ent[2:]), list(clips) + [ids])
+                out = eager()
+            else:  # the clips go straight into their slices of the graph's static frame buffer (one copy launch)
+                n = len(srcs)
+                statics = [ent[1][0][g * Tc:(g + 1) * Tc] for g in range(n)] + [ent[1][1]]
+                out = self._replay(key, (ent[0], statics) + tuple(ent[2:]), srcs + [ids])
         ops.range_snapshot_async(clips[0].device)
 
         def part(v, g):  # clip g's slice of an output of the whole group
@@ -798,15 +812,15 @@ class ReferFormer(nn.Module):
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
-    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None, groups=1):
+    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None, groups=1, shared=False):
         from .pipeline import run_clip
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
-            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T, H0, W0, frames.device, slot), valid=valid,
-                            groups=groups)
+            return run_clip(self, frames, text, img_h, img_w, self._get_arena(T * (groups if shared else 1), H0, W0, frames.device, slot),
+                            valid=valid, groups=groups, shared=shared)
         arena, side_arena, side_stream, arena2, stream2, arena3, stream3, arena4, stream4 = res
         return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False, valid=valid,
-                        groups=groups,
+                        groups=groups, shared=shared,
                         fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
                         fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
@@ -834,7 +848,7 @@ class ReferFormer(nn.Module):
                 st[3])
 
     @torch.no_grad()
-    def hazard_check(self, frames, ids, img_hw=None, valid=None, slot=0, dry=False, groups=1):
+    def hazard_check(self, frames, ids, img_hw=None, valid=None, slot=0, dry=False, groups=1, shared=False):
         """Records ONE pass of the clip's launch program on the capture topology (the same arenas, side streams, forks and
         joins a captured graph is built from) and checks it for races: any two launches not ordered by a fork / join edge
         must touch disjoint memory (tce_rvos_amd/hazard.py).  frames [T,3,H,W] and token ids [1,L] on the GPU.
@@ -845,9 +859,9 @@ class ReferFormer(nn.Module):
         T, _, H0, W0 = frames.shape
         img_h, img_w = (float(H0), float(W0)) if img_hw is None else (float(img_hw[0]), float(img_hw[1]))
         self._ensure_packed()
-        res = self._branch_resources(frames, slot)
+        res = self._branch_resources(types.SimpleNamespace(shape=(T * (groups if shared else 1), 3, H0, W0), device=frames.device), slot)
         st = (frames.clone(), ids.to(frames.device).clone())
-        run = lambda: self._run(st[0], lambda alloc: self._text_plan().forward(st[1], alloc), img_h, img_w, res, valid=valid,  # noqa: E731
+        run = lambda: self._run(st[0], lambda alloc: self._text_plan().forward(st[1], alloc), img_h, img_w, res, valid=valid, shared=shared,  # noqa: E731
                                 groups=groups)
         main = torch.cuda.Stream(device=frames.device)  # like a capture: never the legacy default stream (it syncs with all)
         main.wait_stream(torch.cuda.current_stream())

@@ -109,15 +109,16 @@ class _Fork:
 
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-             fork3=None, valid=None, groups=1):
+             fork3=None, valid=None, groups=1, shared=False):
     """The clip's launch program with the model's own packed-weight routes active (ops.Routes).  valid = (rows, columns) of
     the frames that are not padding (None: un-padded clip)."""
     with ops.routes(model._routes):
-        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid, groups)
+        return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid, groups,
+                         shared)
 
 
 def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-              fork3=None, valid=None, groups=1):
+              fork3=None, valid=None, groups=1, shared=False):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
@@ -134,8 +135,11 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # caption are block-diagonal per clip: the frame tokens' self-attention, the IQT self-attention, the VisionLanguageBlocks'
     # self-attention, every text cross-attention (one folded weight stream per clip), the decoder's start from the clip's
     # sentence feature.  Each clip's result is the B = 1 forward's (the reference MIXES the clips of a batch).
+    # shared = True: the G clips are ONE clip with G captions (the expressions of a video): `frames` holds its Tc frames once, the
+    # backbone runs once and its maps are repeated G times; everything after it is the group program above.
     G = int(groups)
-    T, _, H0, W0 = frames.shape
+    Tb, _, H0, W0 = frames.shape  # frames the backbone sees
+    T = Tb * G if shared else Tb
     if T % G:
         raise ValueError("clip group: frames must hold `groups` clips of equal length")
     Tc = T // G
@@ -325,9 +329,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     lvl_forks.append(fk_)
     if cfg.is_resnet:
         with model.arith("backbone.merge"):  # a ResNet is convolutions only: one site group
-            feats = _resnet_backbone(model, frames, ar, sizes)
+            feats = _resnet_backbone(model, frames, ar, sizes, rep=G if shared else 1)
     else:
-        feats = _swin_backbone(model, frames, ar, sizes, on_stage, G)
+        feats = _swin_backbone(model, frames, ar, sizes, on_stage, 1 if shared else G, rep=G if shared else 1)
 
     _stage("backbone")
     text_fork.join()
@@ -716,12 +720,13 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     return out
 
 
-def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1):
+def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1, rep=1):
     """swin_transformer.py:595-617: returns the four normed stage maps, token-major [T*h*w, C_i].
     Video-Swin (video_swin_transformer.py:678-697): same program with the 3-D window kernel, the (1,4,4) patch
     conv applied per frame, stage outputs taken before the merge and WITHOUT an output norm.
     G > 1 (a clip group): the 2-D windows never leave a frame, so the G clips are simply more frames; the 3-D windows span a
-    clip's frames, so the 3-D window kernel is launched once per clip on that clip's rows."""
+    clip's frames, so the 3-D window kernel is launched once per clip on that clip's rows.
+    rep > 1 (one clip, `rep` captions): every returned map holds the stage's map `rep` times, back to back."""
     cfg, w = model.cfg, model._packed
     A = ar.alloc
     T = frames.shape[0]
@@ -738,7 +743,7 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1):
         H, W = sizes[i]
         ntok = T * H * W
         nH = cfg.num_heads[i]
-        out_i = None if cfg.video else A(ntok, C)
+        out_i = A(rep * ntok, C) if (rep > 1 or not cfg.video) else None
         x_next = None
         if i < len(cfg.depths) - 1:
             H2, W2 = sizes[i + 1]
@@ -801,9 +806,11 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1):
                             ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
             ar.release(m0)
         if cfg.video:
-            feats.append(x)
+            feats.append(x if rep == 1 else ops.tile(x, rep, out=out_i))
         else:
-            ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i)
+            ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i[:ntok])
+            if rep > 1:
+                ops.tile(out_i[:ntok], rep - 1, out=out_i[ntok:])
             feats.append(out_i)
         if on_stage is not None:
             on_stage(i, feats[-1])  # the stage's map is final: work that needs only this map may start beside the rest
@@ -819,7 +826,7 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1):
     return feats
 
 
-def _resnet_backbone(model, frames, ar, sizes):
+def _resnet_backbone(model, frames, ar, sizes, rep=1):
     """models/backbone.py:76-85 over torchvision's bottleneck ResNet (row A11): returns layer1..layer4 maps,
     token-major [T*h*w, 256/512/1024/2048].  Each FrozenBatchNorm2d is folded into the convolution before it
     (model._pack_resnet), so a bottleneck is three (block 0: four) GEMM launches: 1x1 + ReLU, 3x3 (carrying the
@@ -828,7 +835,8 @@ def _resnet_backbone(model, frames, ar, sizes):
     A = ar.alloc
     T = frames.shape[0]
     b = "backbone.0.body."
-    feats = [A(T * h * ww, c) for (h, ww), c in zip(sizes, cfg.num_channels)]
+    full = [A(rep * T * h * ww, c) for (h, ww), c in zip(sizes, cfg.num_channels)]  # rep > 1: each map `rep` times (one clip,
+    feats = [f[:T * h * ww] for f, (h, ww) in zip(full, sizes)]                      # `rep` captions: see _swin_backbone)
     m_all = ar.mark()
     stem, H1, W1 = ops.resnet_stem(frames, w[b + "conv1:f"], w[b + "conv1:b"], alloc=A)
     x, H, W = ops.maxpool3x3s2_cl(stem, T, H1, W1, 64, alloc=A)
@@ -856,7 +864,10 @@ def _resnet_backbone(model, frames, ar, sizes):
             ar.release(m0)
             x, H, W, cin = out, Ho, Wo, 4 * width
     ar.release(m_all)
-    return feats
+    if rep > 1:
+        for f, part in zip(full, feats):
+            ops.tile(part, rep - 1, out=f[part.shape[0]:])
+    return full
 
 
 def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1):

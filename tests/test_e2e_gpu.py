@@ -976,6 +976,32 @@ def test_clip_group_matches_one_clip_at_a_time(models, backbone, G, T, H, W, L):
         assert union == 0 or inter / union > 0.9999
 
 
+@pytest.mark.parametrize("backbone,G,T,H,W", [("swin_t_p4w7", 3, 3, 96, 132), ("swin_t_p4w7", 4, 5, 360, 640),
+                                              ("video_swin_t_p4w7", 2, 4, 96, 128), ("resnet50", 4, 1, 96, 128)])
+def test_expressions_of_one_clip_share_the_backbone(models, backbone, G, T, H, W):
+    """forward_group with the SAME clip tensor G times (G expressions of one video): the backbone runs once, its maps are
+    repeated, the rest is the group program.  Each result = the B = 1 forward of (clip, that caption); the program is race-free."""
+    model = models(backbone, 31)
+    clips, ids = _group_inputs(1, T, H, W, 9)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 50000, (G, 9), generator=g).cuda()
+    tgt = [{"size": torch.tensor([H, W])}]
+    solo = [{k: v.clone() for k, v in model([clips[0]], ids[i:i + 1], tgt).items() if k in GROUP_KEYS} for i in range(G)]
+    runs = []
+    for _ in range(3):  # eager, capture, replay
+        outs = model.forward_group([clips[0]] * G, ids, tgt)
+        torch.cuda.synchronize()
+        runs.append([{k: o[k].clone() for k in GROUP_KEYS} for o in outs])
+    for i in range(G):
+        for k in GROUP_KEYS:
+            ref, got = solo[i][k], runs[0][i][k]
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (i, k)
+            assert torch.equal(runs[1][i][k], got) and torch.equal(runs[2][i][k], got), (i, k, "replay != eager")
+    rep = model.hazard_check(clips[0], ids, (H, W), groups=G, shared=True)
+    assert rep.clean, str(rep)
+
+
 def test_clip_group_clips_do_not_see_each_other(models):
     """Changing clip 1 (frames and caption) must leave clip 0's outputs bit-identical: nothing crosses the clips of a group."""
     model = models("swin_t_p4w7", 31)
