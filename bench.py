@@ -358,7 +358,7 @@ def main():
             C = 1
         if model.use_graph and C_saved == 1 and Gp_saved == 1 and args.gemm_mode != "f32":
             # clip groups (model.forward_group): G independent clips as ONE launch program, each clip's result its B = 1 forward's
-            for gg in (2, 4):
+            for gg in (2, 4, 8):
                 Gp = gg
                 ids_groups = [torch.cat([ids[(k + j) % n_pool] for j in range(Gp)], 0) for k in range(n_pool)]
                 variants[f"value_group{gg}"] = round(n_var * gg / timed(n_var, 4, gather=False), 3)
