@@ -314,14 +314,14 @@ int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed, const flo
                       const float* be_in, float eps_in, const float* g_out, const float* be_out, float eps_out,
                       float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act, tceStream stream);
 
-/* Token-stationary linear layer (csrc/chain.hip), for K in {96,128,192,256} and many rows:
+/* Token-stationary linear layer (csrc/chain.hip), for K in {96,128,192,256,384,512} and many rows:
  *     out[M,N] = LN_out?( epi( LN_in?(x + a2) W^T + bias ) )      epi: act 0 none | 1 ReLU | 2 GELU(erf), then
  *                                                                 res_mode 0 none | 1 "+ res" | 2 "* res"
  * x stays in registers for the whole launch (read once, in full 128-byte lines), W is streamed from a packed copy
  * (tce_rowlin_pack_f32: fp16 hi/lo planes in MFMA-fragment order; W [N,K] nn.Linear layout, N % 32 == 0).
  * a2: optional addend to x (position map): row pitch lda2; a2_rows > 0 = its row is (row % a2_rows).
  * g_in/be_in: LayerNorm over K applied to (x + a2) before the product; g_out/be_out: LayerNorm over N of the result
- * (N = 256 only: out_proj + residual + LayerNorm of the post-norm transformer blocks in one launch).
+ * (N = 256 and K <= 384 only: out_proj + residual + LayerNorm of the post-norm transformer blocks in one launch).
  * batch > 1: grid.y problems with element strides sX, sA2 (0 = shared), sRes, sOut.  out may alias res (not x).
  * Same split-fp16 arithmetic as tce_gemm_f32's default mode.  Reference: the nn.Linear call sites of
  * tce_deformable_transformer.py:439-489,535-548, ops/modules/ms_deform_attn.py:94-101,115, segmentation.py:330-372,

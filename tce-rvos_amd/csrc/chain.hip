@@ -776,7 +776,9 @@ __global__ void __launch_bounds__(256) rowlin_pack_kernel(const float* __restric
   reinterpret_cast<u32x4*>(out)[u] = o;
 }
 
-inline bool rowlin_shape_ok(int N, int K) { return (K == 96 || K == 128 || K == 192 || K == 256 || K == 384) && N > 0 && N % 32 == 0; }
+inline bool rowlin_shape_ok(int N, int K) {
+  return (K == 96 || K == 128 || K == 192 || K == 256 || K == 384 || K == 512) && N > 0 && N % 32 == 0;
+}
 inline long long rowlin_units(int N, int K) {
   const int HP = (2 * (K / 32) + 3) / 4 * 4;
   return (long long)(2 * (N / 32) + 2) * HP * 64;
@@ -797,8 +799,13 @@ void rowlin_launch(const LinArgs& a, int batch, bool row, hipStream_t s) {
     while (nz < ntiles && rb * nz < 160 && ntiles / (nz * 2) >= 2) nz *= 2;  // only launches with few row blocks
   }
   const dim3 grid(tce_cdiv(a.M, 128), batch, nz), block(256);
-  if (row) hipLaunchKernelGGL((rowlin_kernel<K, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((rowlin_kernel<K, false>), grid, block, 0, s, a);
+  if constexpr (K <= 384) {  // (row mode keeps 8 accumulator tiles beside x: no room at K = 512; the entry point rejects it)
+    if (row) {
+      hipLaunchKernelGGL((rowlin_kernel<K, true>), grid, block, 0, s, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((rowlin_kernel<K, false>), grid, block, 0, s, a);
 }
 
 inline bool ffn_shape_ok(int C, int Hd) { return (C == 96 || C == 128 || C == 192 || C == 256) && Hd > 0 && Hd % 32 == 0; }
@@ -1440,7 +1447,7 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
 extern "C" int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K) { return rowlin_shape_ok(N, K) ? rowlin_units(N, K) * 16 : -1; }
 
 extern "C" int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream) {
-  TCE_CHECK_ARG(rowlin_shape_ok(N, K), "tce_rowlin_pack_f32: unsupported shape N=%d K=%d (K in 96/128/192/256, N %% 32 == 0)", N, K);
+  TCE_CHECK_ARG(rowlin_shape_ok(N, K), "tce_rowlin_pack_f32: unsupported shape N=%d K=%d (K in 96/128/192/256/384/512, N %% 32 == 0)", N, K);
   TCE_CHECK_ARG(W && packed && tce_aligned16(packed) && ldw >= K, "tce_rowlin_pack_f32: null / misaligned pointer or ldw < K");
   const long long units = rowlin_units(N, K);
   hipLaunchKernelGGL(rowlin_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W,
@@ -1466,7 +1473,7 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   TCE_CHECK_ARG((!q.g_in || (q.be_in && tce_aligned16(q.g_in) && tce_aligned16(q.be_in))) &&
                     (!q.g_out || (q.be_out && tce_aligned16(q.g_out) && tce_aligned16(q.be_out))),
                 "tce_rowlin_f32: LayerNorm gamma/beta must come in pairs, 16-byte aligned");
-  TCE_CHECK_ARG(!q.g_out || q.N == 256, "tce_rowlin_f32: the output LayerNorm is built for N = 256");
+  TCE_CHECK_ARG(!q.g_out || (q.N == 256 && q.K <= 384), "tce_rowlin_f32: the output LayerNorm is built for N = 256, K <= 384");
   LinArgs a;
   a.x = q.x; a.a2 = q.a2; a.wpk = (const unsigned char*)q.packed; a.bias = q.bias; a.res = q.res; a.out = q.out;
   a.g_in = q.g_in; a.be_in = q.be_in; a.g_out = q.g_out; a.be_out = q.be_out;
@@ -1477,7 +1484,8 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   const int batch = q.batch > 0 ? q.batch : 1;
   const bool row = q.g_out != nullptr;
   hipStream_t s = (hipStream_t)stream;
-  if (q.K == 384) rowlin_launch<384>(a, batch, row, s);  // Swin stage 3 (C = 384): x = 192 registers, one workgroup per CU
+  if (q.K == 512) rowlin_launch<512>(a, batch, row, s);  // Swin-B stage 3 (C = 512): x = 256 registers, one workgroup per CU
+  else if (q.K == 384) rowlin_launch<384>(a, batch, row, s);  // Swin stage 3 (C = 384): x = 192 registers, one workgroup per CU
   else if (q.K == 256) rowlin_launch<256>(a, batch, row, s);
   else if (q.K == 192) rowlin_launch<192>(a, batch, row, s);
   else if (q.K == 128) rowlin_launch<128>(a, batch, row, s);

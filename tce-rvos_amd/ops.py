@@ -764,6 +764,12 @@ def _rowlin_route(w, M, N, K, ldw, batch):
         if rows < 2048 or M < 2048 or N < 384 or rows > ROWLIN384_MAX_ROWS:
             return None
         return _ROUTES.rowlin.get((w.data_ptr(), N, K, ldw, get_gemm_mode()))
+    if K == 512:  # Swin-B stage 3 (16200 rows at config 5): one wave per SIMD, so a tile's epilogue is not hidden -- only the
+        # proj + residual launch wins (48 vs 56 us; norm1 -> qkv 117 vs 121, norm2 -> fc1 + GELU 184 vs 172 us: left on the tiled
+        # kernel; profiles/r04_rowlin_k512.txt)
+        if N != 512 or rows < ROWLIN_MIN_ROWS or M < 2048:
+            return None
+        return _ROUTES.rowlin.get((w.data_ptr(), N, K, ldw, get_gemm_mode()))
     if rows < ROWLIN_MIN_ROWS or M < 2048:
         return None
     if not (K <= 128 and rows >= 32768) and not (K >= 192 and N >= 384 and N != 576):
@@ -943,7 +949,8 @@ def current_routes():
 
 ROWLIN_MIN_ROWS = int(os.environ.get("TCE_ROWLIN_MIN_ROWS", 12000))
 ROWLIN384_MAX_ROWS = int(os.environ.get("TCE_ROWLIN384_MAX_ROWS", 12000))
-ROWLIN_K = (96, 128, 192, 256, 384) if os.environ.get("TCE_ROWLIN_K384", "1") != "0" else (96, 128, 192, 256)  # A/B switch
+ROWLIN_K = (96, 128, 192, 256) + ((384,) if os.environ.get("TCE_ROWLIN_K384", "1") != "0" else ()) \
+    + ((512,) if os.environ.get("TCE_ROWLIN_K512", "1") != "0" else ())  # A/B switches
 
 
 def rowlin_pack(w, N=None, K=None, ldw=None):
