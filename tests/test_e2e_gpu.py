@@ -1002,6 +1002,24 @@ def test_expressions_of_one_clip_share_the_backbone(models, backbone, G, T, H, W
     assert rep.clean, str(rep)
 
 
+def test_run_video_expressions_matches_run_video(models):
+    """The drivers' loop over a video's expressions (inference_ytvos.py:96-113): grouped by caption length, shared backbone;
+    every expression's masks / chosen query = run_video's for that expression alone."""
+    from tce_rvos_amd.video import run_video, run_video_expressions
+    model = models("swin_t_p4w7", 31)
+    H, W, H0, W0 = 96, 128, 180, 240
+    frames = synth_frames(7, H, W, 90).cuda()
+    caps = ["the left zebra", "a person walking a dog", "the right zebra", "the small dog", "a car"]   # lengths 5, 7, 5, 5, 4
+    res = run_video_expressions(model, frames, caps, (H0, W0), clip_size=4, max_group=2)
+    assert len(res) == len(caps)
+    for c, r in zip(caps, res):
+        ref = run_video(model, frames, c, (H0, W0), clip_size=4)
+        assert torch.equal(r["best_query"], ref["best_query"]), c
+        assert r["masks"].shape == ref["masks"].shape == (7, H0, W0)
+        assert (r["masks"] != ref["masks"]).float().mean().item() < 1e-4, c
+        assert float((r["pred_logits"] - ref["pred_logits"]).abs().max()) < 1e-4
+
+
 def test_clip_group_clips_do_not_see_each_other(models):
     """Changing clip 1 (frames and caption) must leave clip 0's outputs bit-identical: nothing crosses the clips of a group."""
     model = models("swin_t_p4w7", 31)
@@ -1036,3 +1054,9 @@ def test_clip_group_rejects_ragged_groups(models):
         model.forward_group([clips[0], clips[1][:2]], ids, tgt)
     with pytest.raises(ValueError):
         model.forward_group(clips, ids[:1], tgt)
+    with pytest.raises(ValueError):   # captions of unequal token length go in separate groups
+        model.forward_group(clips, ["a dog", "a dog running on the grass"], tgt)
+    # string captions of one length: tokenised like forward's
+    outs = model.forward_group(clips, ["the left zebra", "the left zebra"], tgt)
+    solo = model([clips[1]], ["the left zebra"], tgt)
+    assert float((outs[1]["pred_masks"] - solo["pred_masks"]).abs().max()) <= 2e-5 * float(solo["pred_masks"].abs().max()) + 1e-6
