@@ -795,8 +795,8 @@ def splitk_for(M, N, K):
     blocks = ((M + 63) // 64) * ((N + 63) // 64)
     if not SPLITK_ENABLED:
         return 1
-    if M > 128 or blocks >= 96 or K < 512 or N % 4:
-        return 1
+    if M > 512 or blocks >= 96 or K < 512 or N % 4:  # (up to 512 rows: a clip group's decoder / frame-token FFNs, the stride-32
+        return 1                                      # level's 300 rows: 36 -> 12 us at 160-320 x 256 x 2048, tools/fewrow_bench.py rows)
     s = 1
     while s < 16 and blocks * s * 2 <= 384 and K % (s * 2 * 32) == 0 and K // (s * 2) >= 128:
         s *= 2

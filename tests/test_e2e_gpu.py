@@ -486,7 +486,8 @@ def test_run_sharded_world1_on_gpu(models):
     assert tuple(empty.shape) == (0, 3, H, W)
 
 
-def test_two_rank_gloo_rehearsal_on_one_device():
+@pytest.mark.parametrize("group", [1, 2])
+def test_two_rank_gloo_rehearsal_on_one_device(group):
     """bench.py's N > 1 control flow (clip sharding, harness kernel, asynchronous all-gather of uint8 masks, barrier,
     max-over-ranks timing) with two processes sharing this box's one GPU: gloo for the collective, TCE_BENCH_ONE_DEVICE=1
     puts both ranks on cuda:0.  Each rank is a fresh child process (nothing here has touched the GPU on its behalf)."""
@@ -502,12 +503,13 @@ def test_two_rank_gloo_rehearsal_on_one_device():
                    TCE_BENCH_ONE_DEVICE="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
                                        "--steps", "4", "--warmup", "2", "--frames", "2", "--height", "96", "--width", "128",
-                                       "--tokens", "8", "--no-cpu-baseline", "--no-roofline", "--no-variants"],
+                                       "--tokens", "8", "--no-cpu-baseline", "--no-roofline", "--no-variants", "--group", str(group)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     line = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["clips_per_step"] == 2 and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["config"]["clips_per_step"] == 2 * group and line["value"] > 0
+    assert line["collective"]["gathered_shape"][0] == 2 * group and line["collective"]["own_block_matches"]
     assert "all_gather(uint8 masks)" in line["config"]["parallelism"]
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
 

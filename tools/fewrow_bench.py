@@ -28,8 +28,11 @@ def graph_us(fn, n=50):
 
 
 keep = []
-for (R, N, K, ln) in [(40, 256, 256, False), (40, 768, 256, False), (25, 4, 256, False), (40, 386, 256, False),
-                      (32, 2304, 768, False), (32, 3072, 768, False), (100, 256, 256, False)]:
+SHAPES = [(40, 256, 256, False), (40, 768, 256, False), (25, 4, 256, False), (40, 386, 256, False),
+          (32, 2304, 768, False), (32, 3072, 768, False), (100, 256, 256, False)]
+if len(sys.argv) > 1 and sys.argv[1] == "rows":  # clip groups multiply the rows: where does the tiled GEMM take over?
+    SHAPES = [(R, N, K, False) for (N, K) in ((256, 256), (768, 256), (2048, 256), (256, 2048)) for R in (25, 40, 100, 160, 200, 256)]
+for (R, N, K, ln) in SHAPES:
     x = torch.randn(R, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     b = torch.randn(N, device="cuda")
