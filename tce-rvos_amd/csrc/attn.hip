@@ -1061,7 +1061,10 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
   __shared__ __attribute__((aligned(16))) unsigned char sKh[NKMAX * KPITCH], sKl[NKMAX * KPITCH], sVh[HD * VPITCH], sVl[HD * VPITCH];
   __shared__ float sB[TROWS + 1];
   __shared__ int sSrc[NKMAX];  // source token row, -1 padded token, -2 no token
-  __shared__ int sCR[NKMAX];   // code | region id << 16
+  __shared__ int sCR[NKMAX];   // code | region id << 16 (natural order: the query side)
+  // the key side in ACCUMULATOR order: entry kt*32 + 16*hi + r = key kt*32 + crow(r, hi), so the 16 keys of a lane's score
+  // registers are 16 consecutive words (four ds_read_b128 per key tile instead of sixteen ds_read_b32)
+  __shared__ __attribute__((aligned(16))) int sCodeF[NKMAX], sRidF[NKMAX];
   const int N = g.wd * g.wh * g.ww;
   const int tid = threadIdx.x, nthr = 64 * NW;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1093,6 +1096,9 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
     }
     sSrc[n] = src;
     sCR[n] = cr;
+    const int w32 = n & 31, hi_ = (w32 >> 2) & 1, r_ = (w32 & 3) + 4 * (w32 >> 3);  // n = kt*32 + crow(r_, hi_)
+    sCodeF[(n & ~31) + 16 * hi_ + r_] = cr & 0xffff;
+    sRidF[(n & ~31) + 16 * hi_ + r_] = cr >> 16;
   }
   // the table is kept pre-multiplied by log2(e): the softmax below runs in base 2 (v_exp_f32 IS 2^x; one multiply per score saved)
   for (int i = tid; i < table_rows; i += nthr) sB[i] = table[(long long)i * nH + h] * 1.4426950408889634f;
@@ -1130,7 +1136,9 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
     vl[3 * vp] = (unsigned short)(l1 >> 16);
   }
   __syncthreads();
-  const bool masked = (g.sd | g.sh | g.sw) != 0;
+  // the -100 mask separates the regions of the shifted grid's LAST window along each shifted dimension; every other window
+  // lies in region 0 entirely (322 windows at config 3's first stage, 36 of them on the border): no mask arithmetic there
+  const bool masked = (g.sd > 0 && bd == g.Dp / g.wd - 1) || (g.sh > 0 && by == nwy - 1) || (g.sw > 0 && bx == nwx - 1);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 * log2(e): base-2 softmax
   const int koff = ((g.fd - 1) * (2 * g.fh - 1) + (g.fh - 1)) * (2 * g.fw - 1) + (g.fw - 1);
   const int nkt = NKP / 32, nqt = (N + 31) / 32;
@@ -1139,9 +1147,8 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
     const int qc = min(qi, N - 1);
     const int srow = sSrc[qc];
     const int crq = sCR[qc];
-    // query word - key word = (table index) | (region difference << 16): ONE subtraction per score gives both the relative-
-    // position index (low 16 bits; never borrows: code_q + koff >= code_k) and "the -100 mask applies" (high bits != 0)
-    const int cq = crq + koff;
+    // table index = code_q + koff - code_k (never negative); the -100 mask applies where the region ids differ
+    const int cq = (crq & 0xffff) + koff, rq = crq >> 16;
     ah16x8 qh[2], ql[2];
     {
       const float* p = srow >= 0 ? qkv + (long long)srow * C3 + h * HD : qkv_bias + h * HD;
@@ -1179,16 +1186,34 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
       }
       float tmax = -3.0e38f;
       const bool ragged = k0 + 32 > N;  // only the last key tile can hold keys that do not exist (wave-uniform)
+      int kc[16];
+      {
+        const au32x4* cp = reinterpret_cast<const au32x4*>(sCodeF + k0 + 16 * lhi);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = k0 + crow(r, lhi);
-        const int df = cq - sCR[j];
-        float a = st[r] + sB[df & 0xffff];
-        if (masked) a += (df >> 16) != 0 ? -144.26950408889634f : 0.f;  // -100 * log2(e)
-        if (ragged && j >= N) a = -3.0e38f;
-        st[r] = a;
-        tmax = fmaxf(tmax, a);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const au32x4 c4 = cp[q4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) kc[4 * q4 + c] = (int)c4[c];
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] += sB[cq - kc[r]];
+      if (masked) {
+        const au32x4* rp = reinterpret_cast<const au32x4*>(sRidF + k0 + 16 * lhi);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const au32x4 r4 = rp[q4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) st[4 * q4 + c] += (int)r4[c] != rq ? -144.26950408889634f : 0.f;  // -100 * log2(e)
+        }
+      }
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + crow(r, lhi) >= N) st[r] = -3.0e38f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(m, tmax);
       if (__builtin_amdgcn_ballot_w64(mnew > m) != 0) {  // the running maximum of some query moved: rescale (else corr = 1 for all)
