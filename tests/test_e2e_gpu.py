@@ -944,6 +944,7 @@ GROUP_KEYS = ("pred_logits", "pred_boxes", "pred_masks", "memory", "reference_po
                                                 ("swin_t_p4w7", 3, 2, 64, 96, 40),      # > 32 tokens: un-folded text cross-attention
                                                 ("swin_t_p4w7", 2, 5, 360, 640, 32),    # BASELINE config 2 shapes
                                                 ("swin_t_p4w7", 4, 5, 360, 640, 32),
+                                                ("swin_t_p4w7", 8, 5, 360, 640, 32),    # BASELINE config 4's per-GPU batch; 256 caption tokens
                                                 ("video_swin_t_p4w7", 2, 4, 96, 128, 9),  # 3-D windows: one launch per clip
                                                 ("resnet50", 3, 1, 96, 128, 9),
                                                 ("resnet50", 8, 1, 96, 128, 20),        # 160 caption tokens: tiled-GEMM text layers
