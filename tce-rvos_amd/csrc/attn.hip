@@ -7,6 +7,13 @@
 #include "../../include/tce_rvos.h"
 #include "../../include/tce_rvos_debug.h"
 
+// launches KT when `flag` (the single-pass arithmetic) is set, KF otherwise: the mode is a template parameter of the kernels
+#define TCE_BY_SINGLE(flag, KT, KF, ...)              \
+  do {                                                \
+    if (flag) hipLaunchKernelGGL(KT, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(KF, __VA_ARGS__);         \
+  } while (0)
+
 namespace {
 
 constexpr int HD = 32;  // head dim
@@ -304,12 +311,16 @@ __device__ __forceinline__ void attn_split2(const float a, const float b, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
 }
 
-template <int NW, bool KSPLIT>
+// SINGLE: the arithmetic mode (tce_set_gemm_mode(2) = one MFMA per product) as a COMPILE-TIME parameter of the split-fp16 attention
+// kernels: as a run-time flag it put uniform branches around every hi / lo split and in front of the lo-term MFMAs, and the
+// basic-block boundaries kept the scheduler from overlapping the softmax arithmetic with the MFMAs (see ffn_fused_kernel).
+template <int NW, bool KSPLIT, bool SINGLE>
 __global__ void __launch_bounds__(64 * NW) mha_f16x3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, float* __restrict__ O, int nheads,
                                                             int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, long long sQ,
                                                             long long sK, long long sV, long long sO,
-                                                            const uint8_t* __restrict__ kmask, float scale, const int single) {
+                                                            const uint8_t* __restrict__ kmask, float scale) {
+  constexpr int single = SINGLE;
   // KSPLIT: the NW waves of a workgroup own the SAME 32 queries and a quarter of the keys each (private K/V tiles, no
   // workgroup barrier inside the loop), partial (max, sum, O) merged through LDS at the end -- for long key sequences
   // with too few query tiles to fill the chip a wave's serial chain of key tiles is what bounds the launch.
@@ -568,11 +579,12 @@ __global__ void __launch_bounds__(256) mha_planes_kernel(const float* __restrict
       au32x2{(unsigned)rl[0] | ((unsigned)rl[1] << 16), (unsigned)rl[2] | ((unsigned)rl[3] << 16)};
 }
 
-template <bool KSPLIT>
+template <bool KSPLIT, bool SINGLE>
 __global__ void __launch_bounds__(256) mha_presplit_kernel(const float* __restrict__ Q, const unsigned char* __restrict__ ws,
                                                            float* __restrict__ O, int nheads, int Lq, int Lk, int Lkp, int ldq,
                                                            int ldo, long long sQ, long long sO, long long plane,
-                                                           const uint8_t* __restrict__ kmask, float scale, const int single) {
+                                                           const uint8_t* __restrict__ kmask, float scale) {
+  constexpr int single = SINGLE;
   constexpr int KT = 32, NW = 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1048,12 +1060,13 @@ __global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restr
 // [:N,:N] slicing quirk included -- and the -100 region mask are added in registers, the online softmax is in-register
 // + one cross-half shuffle, and P^T is the B operand of O^T = V^T P^T without leaving the registers.
 // ---------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool SINGLE>
 __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float* __restrict__ qkv,
                                                                      const float* __restrict__ qkv_bias,
                                                                      const float* __restrict__ table,
                                                                      float* __restrict__ out, Win3D g, int C, int nH,
-                                                                     int table_rows, int NKP, const int single) {
+                                                                     int table_rows, int NKP) {
+  constexpr int single = SINGLE;
   typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
   // static LDS sized for the nominal window (392 keys -> 416): 134 KB, one workgroup per CU
@@ -1321,14 +1334,14 @@ extern "C" int tce_mha_f32(const float* Q, const float* K, const float* V, float
     const bool ksplit = tiles < 4096 && Lk >= 1024;
     if (ksplit) {
       dim3 gk(tce_cdiv(Lq, 32), batch * nheads);
-      hipLaunchKernelGGL((mha_f16x3_kernel<4, true>), gk, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
-                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+      TCE_BY_SINGLE(single, (mha_f16x3_kernel<4, true, true>), (mha_f16x3_kernel<4, true, false>), gk, dim3(256), 0, (hipStream_t)stream, Q,
+                    K, V, O, nheads, Lq, Lk, ldq, ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
     } else if (nw == 4) {
-      hipLaunchKernelGGL((mha_f16x3_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
-                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+      TCE_BY_SINGLE(single, (mha_f16x3_kernel<4, false, true>), (mha_f16x3_kernel<4, false, false>), grid, dim3(256), 0, (hipStream_t)stream,
+                    Q, K, V, O, nheads, Lq, Lk, ldq, ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
     } else {
-      hipLaunchKernelGGL((mha_f16x3_kernel<1, false>), grid, dim3(64), 0, (hipStream_t)stream, Q, K, V, O, nheads, Lq, Lk, ldq,
-                         ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale, single);
+      TCE_BY_SINGLE(single, (mha_f16x3_kernel<1, false, true>), (mha_f16x3_kernel<1, false, false>), grid, dim3(64), 0, (hipStream_t)stream,
+                    Q, K, V, O, nheads, Lq, Lk, ldq, ldk, ldv, ldo, (long long)sQ, (long long)sK, (long long)sV, (long long)sO, kmask, scale);
     }
     TCE_CHECK_LAUNCH("tce_mha_f32");
     return TCE_OK;
@@ -1368,13 +1381,13 @@ extern "C" int tce_mha_ws_f32(const float* Q, const float* K, const float* V, fl
                      Lkp, ldk, ldv, (long long)sK, (long long)sV, plane, single);
   const long long tiles = (long long)tce_cdiv(Lq, 32) * batch * nheads;
   if (tiles < 4096) {  // too few query tiles to fill the chip: the 4 waves of a workgroup split the keys
-    hipLaunchKernelGGL((mha_presplit_kernel<true>), dim3(tce_cdiv(Lq, 32), batch * nheads), dim3(256), 0, s, Q,
-                       (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
-                       scale, single);
+    TCE_BY_SINGLE(single, (mha_presplit_kernel<true, true>), (mha_presplit_kernel<true, false>), dim3(tce_cdiv(Lq, 32), batch * nheads),
+                  dim3(256), 0, s, Q, (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
+                  scale);
   } else {
-    hipLaunchKernelGGL((mha_presplit_kernel<false>), dim3(tce_cdiv(Lq, 128), batch * nheads), dim3(256), 0, s, Q,
-                       (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
-                       scale, single);
+    TCE_BY_SINGLE(single, (mha_presplit_kernel<false, true>), (mha_presplit_kernel<false, false>), dim3(tce_cdiv(Lq, 128), batch * nheads),
+                  dim3(256), 0, s, Q, (const unsigned char*)ws, O, nheads, Lq, Lk, Lkp, ldq, ldo, (long long)sQ, (long long)sO, plane, kmask,
+                  scale);
   }
   TCE_CHECK_LAUNCH("tce_mha_ws_f32");
   return TCE_OK;
@@ -1410,8 +1423,8 @@ extern "C" int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, co
     // (VALU) runs under the other's MFMAs; the 13 query tiles of a full window take two rounds.
     constexpr int NW = 8;
     const int NKP = (N + 31) / 32 * 32;
-    hipLaunchKernelGGL(window_attn3d_mfma_kernel<NW>, dim3(nwin * nH), dim3(64 * NW), 0, (hipStream_t)stream, qkv,
-                       qkv_bias, bias_table, out, g, C, nH, table_rows, NKP, tce_gemm_single_pass());
+    TCE_BY_SINGLE(tce_gemm_single_pass(), (window_attn3d_mfma_kernel<NW, true>), (window_attn3d_mfma_kernel<NW, false>), dim3(nwin * nH),
+                  dim3(64 * NW), 0, (hipStream_t)stream, qkv, qkv_bias, bias_table, out, g, C, nH, table_rows, NKP);
     TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
     return TCE_OK;
   }

@@ -267,7 +267,11 @@ struct FfnArgs {
   int wdiv;         // batch entries (grid.y) sharing one weight stream: stream index = blockIdx.y / wdiv (>= 1)
 };
 
-template <int C, int WAVES, int ACT>
+// SINGLE (the arithmetic mode, FfnArgs.single at the launch) is a COMPILE-TIME parameter: as a run-time flag it put one uniform
+// branch in front of every step's two lo-term MFMAs (and around every hi / lo split), and the basic-block boundaries kept the
+// scheduler from overlapping a step's loads, DMA and split with its MFMAs: 192 -> 175 us at 24100 rows, 90 -> 79 us for the
+// C = 192 instantiation, the config-2 clip 6.87 -> 6.63 ms (A/B in one call, profiles/r04_single_template.txt).
+template <int C, int WAVES, int ACT, bool SINGLE>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const FfnArgs p) {
   constexpr int KS = C / 16, NT = C / 32;
   constexpr int SLOTS = (1 + 2 * KS + 4 * NT + WAVES - 1) / WAVES;
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   float* const outb = p.out + blockIdx.y * p.sOut;
   float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<C, (ACT >= 3)>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
+  load_x_frags<C, (ACT >= 3)>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, SINGLE);
 
   f32x16 oacc[NT];
 #pragma unroll
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
   tce_amax_t amax = 0;
-  const int single = p.single;
+  constexpr int single = SINGLE;
   h16x8 hh0, hl0, hh1, hl1;  // H^T of the previous chunk as B fragments (k-steps 0 and 1)
 #pragma unroll
   for (int j = 0; j < 8; ++j) hh0[j] = hl0[j] = hh1[j] = hl1[j] = (_Float16)0.f;
@@ -572,7 +576,7 @@ struct LinArgs {
 // K = 96 (Swin-T stage 0) is compiled for THREE workgroups per CU (168 registers, 43 KB of LDS): at config 2 the stage has
 // 72000 rows = 563 row blocks, one more than two per CU hold (512) -- a second, nearly empty round.  47.7 -> 38.5 us for the
 // norm1 -> qkv launch (profiles/r03_rowlin_occupancy.txt).
-template <int K, bool ROW>
+template <int K, bool ROW, bool SINGLE>  // SINGLE: compile-time arithmetic mode, see ffn_fused_kernel
 __global__ void __launch_bounds__(256, (ROW || K > 256) ? 1 : (K <= 96 ? 3 : 2)) rowlin_kernel(const LinArgs p) {
   // The ring holds HALF blocks (the first / second K/32 k-steps of a 32-channel tile, hi and lo pieces interleaved,
   // padded to a multiple of 4 pieces so that every wave issues the same number of DMAs): three half-stages, the DMA of
@@ -626,8 +630,8 @@ __global__ void __launch_bounds__(256, (ROW || K > 256) ? 1 : (K <= 96 ? 3 : 2))
 
   float* const wt = reinterpret_cast<float*>(smem + 3 * HSTAGE + wave * WT_BYTES);
   h16x8 xh[KS], xl[KS];
-  load_x_frags<K>(x, p.ldx, a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, p.single);
-  const int single = p.single;
+  load_x_frags<K>(x, p.ldx, a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, SINGLE);
+  constexpr int single = SINGLE;
   tce_amax_t amax = 0;
   if (stamps) stamps[6] = (long long)__builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -801,11 +805,13 @@ void rowlin_launch(const LinArgs& a, int batch, bool row, hipStream_t s) {
   const dim3 grid(tce_cdiv(a.M, 128), batch, nz), block(256);
   if constexpr (K <= 384) {  // (row mode keeps 8 accumulator tiles beside x: no room at K = 512; the entry point rejects it)
     if (row) {
-      hipLaunchKernelGGL((rowlin_kernel<K, true>), grid, block, 0, s, a);
+      if (a.single) hipLaunchKernelGGL((rowlin_kernel<K, true, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((rowlin_kernel<K, true, false>), grid, block, 0, s, a);
       return;
     }
   }
-  hipLaunchKernelGGL((rowlin_kernel<K, false>), grid, block, 0, s, a);
+  if (a.single) hipLaunchKernelGGL((rowlin_kernel<K, false, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((rowlin_kernel<K, false, false>), grid, block, 0, s, a);
 }
 
 inline bool ffn_shape_ok(int C, int Hd) { return (C == 96 || C == 128 || C == 192 || C == 256) && Hd > 0 && Hd % 32 == 0; }
@@ -819,8 +825,13 @@ inline long long ffn_units(int C, int Hd) { return (long long)(Hd / 32 + 2) * ff
 template <int C, int WAVES>
 void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
   const dim3 grid(tce_cdiv(a.M, 32 * WAVES), batch), block(64 * WAVES);
-  if (act == 1) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1>), grid, block, 0, s, a);
-  else if (act == 2) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 2>), grid, block, 0, s, a);
+  if (a.single) {
+    if (act == 1) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, true>), grid, block, 0, s, a);
+    else if (act == 2) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 2, true>), grid, block, 0, s, a);
+  } else {
+    if (act == 1) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, false>), grid, block, 0, s, a);
+    else if (act == 2) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 2, false>), grid, block, 0, s, a);
+  }
 }
 
 // Text cross-attention as an FFN-shaped chain (see tce_xattn_prepare_f32 in the header): folds the per-clip key / value
@@ -1438,8 +1449,13 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   a.wdiv = q.w_div > 0 ? q.w_div : 1;
   const int batch = q.batch > 0 ? q.batch : 1;
   const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
-  if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4>), grid, block, 0, (hipStream_t)stream, a);
+  if (a.single) {
+    if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4, true>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3, false>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4, false>), grid, block, 0, (hipStream_t)stream, a);
+  }
   TCE_CHECK_LAUNCH("tce_xattn_fused_f32");
   return TCE_OK;
 }

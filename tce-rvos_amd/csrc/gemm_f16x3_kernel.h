@@ -76,10 +76,12 @@ static __device__ int g_epi_lds = 1;  // tuning aid: 1 = LDS-staged coalesced ep
 // register ring (loads are unconditional -- clamped addresses, validity applied at commit -- and the steady-state
 // loop is branch-free, so the compiler emits exact counted vmcnt waits): a K step no longer pays a full memory
 // round trip, which is what bounds the small / short-K problems of this path.
-template <int BM, int BN, int WAVES_M, bool CONV, bool HAS_A2, int DEPTH>
+// SINGLE (tce_set_gemm_mode(2): one MFMA per product) is a compile-time parameter: as a run-time flag it put a uniform branch
+// in front of every tile's two lo-term MFMAs and around every hi / lo split (see ffn_fused_kernel in chain.hip).
+template <int BM, int BN, int WAVES_M, bool CONV, bool HAS_A2, int DEPTH, bool SINGLE>
 __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
-    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n, int* const range_flag,
-                      const int single) {
+    gemm_f16x3_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n, int* const range_flag) {
+  constexpr int single = SINGLE;
   constexpr int NT = 128 * WAVES_M;                   // threads: WAVES_M x 2 waves
   constexpr int RP = NT / 8;                          // tile rows covered by one loader pass
   constexpr int WM = BM / WAVES_M, WN = BN / 2;
@@ -304,12 +306,16 @@ template <int BM, int BN, int WAVES_M, int DEPTH>
 void launch(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1), block(128 * WAVES_M);
-  if (a.conv)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
-  else if (a.A2)
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
-  else
-    hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH>), grid, block, 0, s, a, tiles_m, tiles_n, tce_range_flag(), tce_gemm_single_pass());
+  int* const rf = tce_range_flag();
+  if (tce_gemm_single_pass()) {
+    if (a.conv) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+    else if (a.A2) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+  } else {
+    if (a.conv) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+    else if (a.A2) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+  }
 }
 
 

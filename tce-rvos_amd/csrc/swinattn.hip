@@ -107,7 +107,7 @@ struct SwinCfg {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int C>
+template <int C, bool SINGLE>  // SINGLE: the arithmetic mode as a compile-time parameter (no uniform branches around the lo-term MFMAs)
 __global__ void __launch_bounds__(256, SwinCfg<C>::WG_PER_CU) swin_attn_fused_kernel(const SwinArgs p) {
   using K_ = SwinCfg<C>;
   constexpr int KS = K_::KS, NTL = K_::NTL, NH = K_::NH, HSTEPS = K_::HSTEPS, G = K_::G, STAGE = K_::STAGE, SLOTS = K_::SLOTS;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, SwinCfg<C>::WG_PER_CU) swin_attn_fused_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int it = wave >> 1, qt = wave & 1;  // window slot of the workgroup, query / key tile of the window
   const int l31 = lane & 31, hf = lane >> 5;
-  const int single = p.single;
+  constexpr int single = SINGLE;
   if (p.T < 0) reinterpret_cast<u32x4*>(smem)[tid] = u32x4{0u, 0u, 0u, 0u};  // a visible store (see ffn_fused_kernel)
 
   // ---- weight stream: this wave moves pieces wave, wave + 4, ... of every stage
@@ -446,7 +446,8 @@ long long swin_units(int C) { return swin_real_units(C) + (long long)((C <= SWIN
 
 template <int C>
 void swin_launch(const SwinArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(swin_attn_fused_kernel<C>, dim3(tce_cdiv(a.nwin, 2)), dim3(256), 0, s, a);
+  if (a.single) hipLaunchKernelGGL((swin_attn_fused_kernel<C, true>), dim3(tce_cdiv(a.nwin, 2)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((swin_attn_fused_kernel<C, false>), dim3(tce_cdiv(a.nwin, 2)), dim3(256), 0, s, a);
 }
 
 }  // namespace

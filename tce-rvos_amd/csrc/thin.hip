@@ -30,7 +30,7 @@ struct ThinArgs {
 
 __device__ __forceinline__ int crow_t(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <bool PRO>
+template <bool PRO, bool SINGLE>  // SINGLE: the arithmetic mode as a compile-time parameter (see ffn_fused_kernel, chain.hip)
 __global__ void __launch_bounds__(256) thin_partials_kernel(const ThinArgs p) {
   // per wave: one staging tile for W and one for x (32 rows x 32 floats, 144-byte pitch: conflict-free for the row-of-8-lanes
   // writes and the row-per-lane fragment reads alike, see frag.h); the tiles are reused by the wave's two 32-wide K chunks
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(256) thin_partials_kernel(const ThinArgs p) {
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(tw + l31 * WT_PITCH + 16 * st + 8 * hf + 4);
       const float xf[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       const float wf[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-      const HL a = split8(xf, p.single), b = split8(wf, p.single);
-      if (!p.single) {
+      const HL a = split8(xf, SINGLE), b = split8(wf, SINGLE);
+      if (!SINGLE) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
       }
@@ -147,8 +147,13 @@ extern "C" int tce_thin_partials_f32(const float* x, int64_t ldx, int32_t xsplit
   a.x = x; a.bias_x = bias_x; a.W = W; a.ws = ws; a.ldx = ldx; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   a.xsplits = xsplits; a.act_x = act_x; a.single = tce_gemm_single_pass();
   const dim3 grid(N / 32, tce_cdiv(M, 32), K / 256);
-  if (xsplits > 0) hipLaunchKernelGGL(thin_partials_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(thin_partials_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (a.single) {
+    if (xsplits > 0) hipLaunchKernelGGL((thin_partials_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((thin_partials_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (xsplits > 0) hipLaunchKernelGGL((thin_partials_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((thin_partials_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   TCE_CHECK_LAUNCH("tce_thin_partials_f32");
   return TCE_OK;
 }
