@@ -3,6 +3,7 @@
 // latency/LDS-oriented VALU kernels: one query row per lane (q and the output row live in registers), K/V
 // tiles staged in LDS and read back as wave-uniform (broadcast) ds_read_b128, scores of a whole tile kept
 // in registers so softmax needs one rescale per tile and no cross-lane traffic.
+#include <type_traits>
 #include "common.h"
 #include "../../include/tce_rvos.h"
 #include "../../include/tce_rvos_debug.h"
@@ -1182,7 +1183,10 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m = -3.0e38f, l = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one key tile; MASKED / RAGGED are compile-time so that the tile body is ONE basic block (plus the rescale): a run-time test in
+    // the middle keeps the scheduler from overlapping the softmax arithmetic of a tile with the MFMAs around it
+    auto key_tile = [&](const int kt, auto masked_c, auto ragged_c) {
+      constexpr bool MASKED = decltype(masked_c)::value, RAGGED = decltype(ragged_c)::value;
       const int k0 = kt * 32;
       f32x16 st;
 #pragma unroll
@@ -1198,7 +1202,6 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
         st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], st, 0, 0, 0);
       }
       float tmax = -3.0e38f;
-      const bool ragged = k0 + 32 > N;  // only the last key tile can hold keys that do not exist (wave-uniform)
       int kc[16];
       {
         const au32x4* cp = reinterpret_cast<const au32x4*>(sCodeF + k0 + 16 * lhi);
@@ -1211,7 +1214,7 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] += sB[cq - kc[r]];
-      if (masked) {
+      if (MASKED) {
         const au32x4* rp = reinterpret_cast<const au32x4*>(sRidF + k0 + 16 * lhi);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -1220,7 +1223,7 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
           for (int c = 0; c < 4; ++c) st[4 * q4 + c] += (int)r4[c] != rq ? -144.26950408889634f : 0.f;  // -100 * log2(e)
         }
       }
-      if (ragged) {
+      if (RAGGED) {  // only the last key tile can hold keys that do not exist
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (k0 + crow(r, lhi) >= N) st[r] = -3.0e38f;
@@ -1262,6 +1265,18 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_, bh_, o, 0, 0, 0);
       }
       m = mnew;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const bool last_ragged = nkt * 32 > N;
+    if (masked) {
+      for (int kt = 0; kt + 1 < nkt; ++kt) key_tile(kt, T_{}, F_{});
+      if (last_ragged) key_tile(nkt - 1, T_{}, T_{});
+      else key_tile(nkt - 1, T_{}, F_{});
+    } else {
+      for (int kt = 0; kt + 1 < nkt; ++kt) key_tile(kt, F_{}, F_{});
+      if (last_ragged) key_tile(nkt - 1, F_{}, T_{});
+      else key_tile(nkt - 1, F_{}, F_{});
     }
     l += __shfl_xor(l, 32, 64);
     if (qi < N && srow >= 0) {
