@@ -1341,7 +1341,20 @@ __global__ void __launch_bounds__(256) patch_embed_mfma_kernel(const float* __re
 
 }  // namespace
 
+// The library builds this file as TWO translation units (chain_ffn.hip: TCE_CHAIN_PART 1, chain_rowlin.hip: TCE_CHAIN_PART 2) so that
+// the fused-FFN family and the token-stationary linear family -- each a few dozen instantiations -- compile in parallel; the
+// kernel templates above are shared text, only the entry points (= the instantiation sites) are divided.  Compiled directly
+// (tools/ffn_ablate.py) it is one unit with everything.
+#ifndef TCE_CHAIN_PART
+#define TCE_CHAIN_PART 0
+#endif
+int tce_chain_rowlin_set_stamps(long long* dev_buf);
+
+#if TCE_CHAIN_PART != 2
 extern "C" int tce_debug_ffn_set_stamp_buffer(long long* dev_buf) {
+#if TCE_CHAIN_PART == 1
+  if (tce_chain_rowlin_set_stamps(dev_buf) != 0) return -1;  // the other translation unit's copy of the pointer
+#endif
   return hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_stamps), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -1;
 }
 
@@ -1460,6 +1473,13 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   return TCE_OK;
 }
 
+#endif  // TCE_CHAIN_PART != 2
+
+#if TCE_CHAIN_PART != 1
+int tce_chain_rowlin_set_stamps(long long* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_stamps), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int64_t tce_rowlin_packed_bytes(int32_t N, int32_t K) { return rowlin_shape_ok(N, K) ? rowlin_units(N, K) * 16 : -1; }
 
 extern "C" int tce_rowlin_pack_f32(const float* W, int64_t ldw, void* packed, int32_t N, int32_t K, tceStream stream) {
@@ -1510,6 +1530,9 @@ extern "C" int tce_rowlin_f32(const tceRowLinArgs* args, tceStream stream) {
   return TCE_OK;
 }
 
+#endif  // TCE_CHAIN_PART != 1
+
+#if TCE_CHAIN_PART != 2
 extern "C" int64_t tce_conv3x3_packed_bytes(int32_t Cin, int32_t N) { return conv3x3_shape_ok(Cin, N) ? conv3x3_units(Cin) * 16 : -1; }
 
 extern "C" int tce_conv3x3_pack_f32(const float* w, void* packed, int32_t Cin, int32_t N, tceStream stream) {
@@ -1554,3 +1577,4 @@ bool tce_patch_embed_mfma(const float* frames, const float* w, const float* b, c
   else hipLaunchKernelGGL((patch_embed_mfma_kernel<6>), grid, block, 0, s, frames, w, b, gamma, beta, out, H, W, eps, (int)ntok, Hp, Wp, rf, single);
   return true;
 }
+#endif  // TCE_CHAIN_PART != 2
