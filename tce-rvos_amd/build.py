@@ -17,7 +17,8 @@ OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtce_rvos.so")
 # slowest first (they gate the parallel build): the GEMM translation units carry one epilogue body per (act, res) combination
-SOURCES = ["chain_ffn.hip", "chain_rowlin.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
+SOURCES = ["gemm_f16x3_big_256_split.hip", "gemm_f16x3_big_256_single.hip", "gemm_f16x3_big_128_split.hip", "gemm_f16x3_big_128_single.hip",
+           "chain_ffn.hip", "chain_rowlin.hip", "gemm_f16x3_big.hip", "gemm_f16x3_small.hip", "gemm.hip", "attn.hip", "misc.hip", "norm.hip", "msda.hip",
            "text.hip", "resnet.hip", "frontend.hip", "fewrow.hip", "swinattn.hip", "thin.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + \
@@ -35,7 +36,7 @@ def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     # chain.hip is text shared by two translation units (chain_ffn.hip / chain_rowlin.hip): a dependency like a header
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "tce_rvos.h"),
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + [os.path.join(HERE, "..", "include", "tce_rvos.h"),
                                                              os.path.join(CSRC, "chain.hip")]
     objs, todo = [], []
     for s in SOURCES:

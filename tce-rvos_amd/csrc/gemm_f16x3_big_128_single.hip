@@ -1,0 +1,7 @@
+// Split-fp16 GEMM, 128x128 tile (4 waves), single-pass fp16 arithmetic (see gemm_f16x3_big_part.inc)
+#define PART_NAME p128_single
+#define PART_BM 128
+#define PART_BN 128
+#define PART_WM 2
+#define PART_SINGLE true
+#include "gemm_f16x3_big_part.inc"

@@ -302,20 +302,21 @@ __global__ void __launch_bounds__(128 * WAVES_M, WAVES_M == 2 ? 2 : 1)
   }
 }
 
-template <int BM, int BN, int WAVES_M, int DEPTH>
-void launch(const tceGemmArgs& a, hipStream_t s) {
+// the three operand forms (implicit-GEMM convolution, second addend, plain) of one tile in ONE arithmetic mode
+template <int BM, int BN, int WAVES_M, int DEPTH, bool SINGLE>
+void launch_mode(const tceGemmArgs& a, hipStream_t s) {
   const int tiles_m = tce_cdiv(a.M, BM), tiles_n = tce_cdiv(a.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, a.batch > 0 ? a.batch : 1), block(128 * WAVES_M);
   int* const rf = tce_range_flag();
-  if (tce_gemm_single_pass()) {
-    if (a.conv) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-    else if (a.A2) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH, true>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-  } else {
-    if (a.conv) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-    else if (a.A2) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH, false>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
-  }
+  if (a.conv) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, true, false, DEPTH, SINGLE>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+  else if (a.A2) hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, true, DEPTH, SINGLE>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+  else hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WAVES_M, false, false, DEPTH, SINGLE>), grid, block, 0, s, a, tiles_m, tiles_n, rf);
+}
+
+template <int BM, int BN, int WAVES_M, int DEPTH>
+void launch(const tceGemmArgs& a, hipStream_t s) {
+  if (tce_gemm_single_pass()) launch_mode<BM, BN, WAVES_M, DEPTH, true>(a, s);
+  else launch_mode<BM, BN, WAVES_M, DEPTH, false>(a, s);
 }
 
 
