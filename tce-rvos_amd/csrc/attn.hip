@@ -1061,7 +1061,9 @@ __global__ void __launch_bounds__(256) window_attn3d_kernel(const float* __restr
 // [:N,:N] slicing quirk included -- and the -100 region mask are added in registers, the online softmax is in-register
 // + one cross-half shuffle, and P^T is the B operand of O^T = V^T P^T without leaving the registers.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, bool SINGLE>
+// NKMAX / TROWS size the static LDS: (416, 15*13*13) = the nominal (8,7,7) video window, 134 KB, one workgroup of 8 waves per CU;
+// (64, 13*13) = a 2-D Swin window (tce_window_attn_f32 runs it as a (1,7,7) window of this kernel): 20 KB, 2 waves per workgroup.
+template <int NW, int NKMAX, int TROWS, bool SINGLE>
 __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float* __restrict__ qkv,
                                                                      const float* __restrict__ qkv_bias,
                                                                      const float* __restrict__ table,
@@ -1070,8 +1072,7 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
   constexpr int single = SINGLE;
   typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
-  // static LDS sized for the nominal window (392 keys -> 416): 134 KB, one workgroup per CU
-  constexpr int KPITCH = 80, NKMAX = 416, VPITCH = NKMAX * 2 + 8, TROWS = 15 * 13 * 13;
+  constexpr int KPITCH = 80, VPITCH = NKMAX * 2 + 8;
   __shared__ __attribute__((aligned(16))) unsigned char sKh[NKMAX * KPITCH], sKl[NKMAX * KPITCH], sVh[HD * VPITCH], sVl[HD * VPITCH];
   __shared__ float sB[TROWS + 1];
   __shared__ int sSrc[NKMAX];  // source token row, -1 padded token, -2 no token
@@ -1294,8 +1295,10 @@ __global__ void __launch_bounds__(64 * NW) window_attn3d_mfma_kernel(const float
 }  // namespace
 
 static int g_window_attn_mfma = 1;  // tuning aid (tce_debug_window_attn_set_mfma): 0 = the VALU kernel
-extern "C" int tce_debug_window_attn_set_mfma(int32_t on) {
-  g_window_attn_mfma = on;
+static int g_window_attn_2d_split = 1;  // tuning aid (tce_debug_window_attn_set_mfma(2 / 3)): 0 = 2-D windows on the exact-fp32 MFMA kernel
+extern "C" int tce_debug_window_attn_set_mfma(int32_t on) {  // 0 VALU kernels, 1 default, 2 = 1 with 2-D windows on the exact-fp32 MFMA kernel
+  g_window_attn_mfma = on != 0;
+  g_window_attn_2d_split = on != 2;
   return TCE_OK;
 }
 
@@ -1310,6 +1313,23 @@ extern "C" int tce_window_attn_f32(const float* qkv, const float* qkv_bias, cons
                 "tce_window_attn_f32: pointers must be 16-byte aligned");
   const int nWy = (H + 6) / 7, nWx = (W + 6) / 7;
   const long long total = (long long)T * nWy * nWx * nH;
+  if (g_window_attn_mfma && g_window_attn_2d_split && tce_get_gemm_mode() != 0) {
+    // split-fp16 modes: a 2-D Swin window IS a (1,7,7) window of the 3-D kernel (same roll, same padding rule -- a padded token
+    // carries qkv = bias --, same region mask; relative-position index (dy+6)*13 + (dx+6) = the kernel's code difference with the
+    // nominal window (1,7,7)): 49 keys in two tiles, two waves per (window, head), 20 KB of LDS -- five times fewer MFMA cycles than
+    // the exact-fp32 kernel below and no per-score index arithmetic (profiles/r04_window_attn2d.txt)
+    Win3D g;
+    g.D = T; g.H = H; g.W = W;
+    g.wd = 1; g.wh = 7; g.ww = 7;
+    g.sd = 0; g.sh = shift; g.sw = shift;
+    g.Dp = T; g.Hp = nWy * 7; g.Wp = nWx * 7;
+    g.fd = 1; g.fh = 7; g.fw = 7;
+    TCE_CHECK_ARG(total < (1ll << 31), "tce_window_attn_f32: too many (window, head) items");
+    TCE_BY_SINGLE(tce_gemm_single_pass(), (window_attn3d_mfma_kernel<2, 64, 13 * 13, true>), (window_attn3d_mfma_kernel<2, 64, 13 * 13, false>),
+                  dim3((unsigned)total), dim3(128), 0, (hipStream_t)stream, qkv, qkv_bias, bias_table, out, g, C, nH, 13 * 13, 64);
+    TCE_CHECK_LAUNCH("tce_window_attn_f32");
+    return TCE_OK;
+  }
   if (g_window_attn_mfma)
     hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(tce_cdiv(total, 2)), dim3(256), 0, (hipStream_t)stream, qkv, qkv_bias,
                        bias_table, out, T, H, W, C, nH, shift, nWy, nWx, total);
@@ -1438,8 +1458,9 @@ extern "C" int tce_window_attn3d_f32(const float* qkv, const float* qkv_bias, co
     // (VALU) runs under the other's MFMAs; the 13 query tiles of a full window take two rounds.
     constexpr int NW = 8;
     const int NKP = (N + 31) / 32 * 32;
-    TCE_BY_SINGLE(tce_gemm_single_pass(), (window_attn3d_mfma_kernel<NW, true>), (window_attn3d_mfma_kernel<NW, false>), dim3(nwin * nH),
-                  dim3(64 * NW), 0, (hipStream_t)stream, qkv, qkv_bias, bias_table, out, g, C, nH, table_rows, NKP);
+    TCE_BY_SINGLE(tce_gemm_single_pass(), (window_attn3d_mfma_kernel<NW, 416, 15 * 13 * 13, true>),
+                  (window_attn3d_mfma_kernel<NW, 416, 15 * 13 * 13, false>), dim3(nwin * nH), dim3(64 * NW), 0, (hipStream_t)stream, qkv,
+                  qkv_bias, bias_table, out, g, C, nH, table_rows, NKP);
     TCE_CHECK_LAUNCH("tce_window_attn3d_f32");
     return TCE_OK;
   }

@@ -204,6 +204,23 @@ def test_window_attention(ops, T, H, W, nH, shift):
     finally:
         lib().tce_debug_window_attn_set_mfma(1)
     close(out2, ref, 1e-4, 1e-4)
+    # the exact-fp32 matrix-core kernel (what exact-fp32 mode runs; in the split modes the window goes through the (1,7,7) form of
+    # the 3-D split-fp16 kernel): both within fp32 round-off of each other
+    lib().tce_debug_window_attn_set_mfma(2)
+    try:
+        out3 = ops.window_attn(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
+                               C, nH, shift)
+    finally:
+        lib().tce_debug_window_attn_set_mfma(1)
+    close(out3, ref, 1e-4, 1e-4)
+    assert float((out3 - out).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+    ops.set_gemm_mode("f32")
+    try:
+        out4 = ops.window_attn(dev(qkv), dev(sd["attn.qkv.bias"]), dev(sd["attn.relative_position_bias_table"]), T, H, W,
+                               C, nH, shift)
+    finally:
+        ops.set_gemm_mode("f16x3")
+    assert torch.equal(out4, out3)
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 2304, 768), (32, 768, 3072), (7, 768, 768), (100, 3072, 768), (1, 32, 256)])
