@@ -428,8 +428,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
             asm("v_max_f32_e32 %0, 0, %1" : "=v"(v1) : "v"(v1));
           }
           if (ACT == 2) {
-            v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f));
-            v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
+            v0 = tce_gelu(v0);
+            v1 = tce_gelu(v1);
           }
           amax = max(amax, max(tce_absbits(v0), tce_absbits(v1)));
           const fp16x2_t a = single ? fp16x2_t{(__fp16)v0, (__fp16)v1} : __builtin_amdgcn_cvt_pkrtz(v0, v1);
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(256, (ROW || K > 256) ? 1 : (K <= 96 ? 3 : 2))
       for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
     } else if (p.act == 2) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.5f * acc[i] * (1.f + erff(acc[i] * 0.70710678118654752440f));
+      for (int i = 0; i < 16; ++i) acc[i] = tce_gelu(acc[i]);
     }
   };
   // bias, activation, residual (activation sits between bias and residual, as in tce_gemm_f32)

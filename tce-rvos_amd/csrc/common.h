@@ -61,3 +61,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (bid >> 3);
 }
+
+#if defined(__HIPCC__)
+// erf(x), BRANCH-FREE.  The device library's erff takes one of two paths per lane (|x| < 1: odd polynomial; else 1 - exp(-poly)) under
+// exec masks -- inside a software-pipelined MFMA loop (GELU of the Swin MLPs) that is a pair of divergent branches per value, and a
+// wave holds values of both kinds nearly always.  Same two polynomials (the library's coefficients), both evaluated, one select;
+// the exponential is one v_exp_f32 of the rounded product (|error| <= 1e-7 absolute, one ulp of the result, in [0.84, 1)).
+__device__ __forceinline__ float tce_erff(const float x) {
+  const float ax = __builtin_fabsf(x);
+  float p = __builtin_fmaf(ax, __builtin_bit_cast(float, 0x378e98abu), __builtin_bit_cast(float, 0xb9c68948u));
+  p = __builtin_fmaf(ax, p, __builtin_bit_cast(float, 0x3b7cd369u));
+  p = __builtin_fmaf(ax, p, __builtin_bit_cast(float, 0xbcc618b2u));
+  p = __builtin_fmaf(ax, p, __builtin_bit_cast(float, 0x3dda74e4u));
+  p = __builtin_fmaf(ax, p, __builtin_bit_cast(float, 0x3f228afdu));
+  p = __builtin_fmaf(ax, p, __builtin_bit_cast(float, 0x3e03c728u));
+  const float t = __builtin_fmaf(ax, p, ax);
+  const float big = 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * t);
+  const float s = x * x;
+  float q = __builtin_fmaf(s, __builtin_bit_cast(float, 0xba1345e1u), __builtin_bit_cast(float, 0x3ba10414u));
+  q = __builtin_fmaf(s, q, __builtin_bit_cast(float, 0xbcdac9b8u));
+  q = __builtin_fmaf(s, q, __builtin_bit_cast(float, 0x3de703beu));
+  q = __builtin_fmaf(s, q, __builtin_bit_cast(float, 0xbec09330u));
+  q = __builtin_fmaf(s, q, __builtin_bit_cast(float, 0x3e0375d0u));
+  const float small = __builtin_fmaf(ax, q, ax);
+  return __builtin_copysignf(ax < 1.0f ? small : big, x);
+}
+// GELU (erf form, nn.GELU's default)
+__device__ __forceinline__ float tce_gelu(const float v) { return 0.5f * v * (1.f + tce_erff(v * 0.70710678118654752440f)); }
+#endif

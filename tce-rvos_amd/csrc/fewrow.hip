@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
         float v = acc[i] + bv;
         if (sg.act == 1) v = fmaxf(v, 0.f);
         if (sg.act == 2) v = 1.0f / (1.0f + __expf(-v));
-        if (sg.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (sg.act == 3) v = tce_gelu(v);
         if (s == 0 && p.res) v += p.res[(long long)(r0 + r) * p.ldres + n];
         sg.out[(long long)(r0 + r) * sg.ldo + n] = v;
       }

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   for (int c = 0; c < 4; ++c) {
     float x = v[c] + (bias ? bias[n + c] : 0.f);
     if (act == 1) x = fmaxf(x, 0.f);
-    if (act == 2) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    if (act == 2) x = tce_gelu(x);
     if (res_mode == 1) x += res[(long long)m * ldres + n + c];
     if (res_mode == 2) x *= res[(long long)m * ldres + n + c];
     if (act == 3) x = fmaxf(x, 0.f);

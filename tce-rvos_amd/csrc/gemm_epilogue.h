@@ -36,7 +36,7 @@ __device__ __forceinline__ void tce_epi_store(const f32x16& x, const float bv, c
     const int row = row0 + (r & 3) + 8 * (r >> 2);
     float v = x[r] + bv;
     if (ACT == 1) v = fmaxf(v, 0.f);
-    if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (ACT == 2) v = tce_gelu(v);
     if (RES == 1) v += rv[r];
     if (RES == 2) v *= rv[r];
     if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
@@ -71,7 +71,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
       for (int c = 0; c < 4; ++c) {
         float v = x[4 * g + c] + (bias ? bv[g][c] : 0.f);
         if (ACT == 1) v = fmaxf(v, 0.f);
-        if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (ACT == 2) v = tce_gelu(v);
         if (RES == 1) v += rv[g][c];
         if (RES == 2) v *= rv[g][c];
         if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
@@ -89,7 +89,7 @@ __device__ __forceinline__ void tce_epi_store_t(const f32x16& x, const float* __
         if (n < N) {
           float v = x[4 * g + c] + (bias ? bias[n] : 0.f);
           if (ACT == 1) v = fmaxf(v, 0.f);
-          if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+          if (ACT == 2) v = tce_gelu(v);
           if (RES == 1) v += rrow[n];
           if (RES == 2) v *= rrow[n];
           if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual
@@ -152,7 +152,7 @@ __device__ __forceinline__ void tce_epi_store_lds(const f32x16& x, float* __rest
     for (int c = 0; c < 4; ++c) {
       float v = xv[it][c] + bv[c];
       if (ACT == 1) v = fmaxf(v, 0.f);
-      if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+      if (ACT == 2) v = tce_gelu(v);
       if (RES == 1) v += rv[it][c];
       if (RES == 2) v *= rv[it][c];
       if (ACT == 3) v = fmaxf(v, 0.f);  // ReLU after the residual

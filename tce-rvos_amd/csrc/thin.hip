@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) thin_partials_kernel(const ThinArgs p) {
           for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
         } else if (p.act_x == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = 0.5f * a[e] * (1.f + erff(a[e] * 0.70710678118654752440f));
+          for (int e = 0; e < 4; ++e) a[e] = tce_gelu(a[e]);
         }
         xv[c][i] = a;
       }

@@ -223,6 +223,29 @@ def test_window_attention(ops, T, H, W, nH, shift):
     assert torch.equal(out4, out3)
 
 
+def test_gelu_branch_free_erf_is_fp32_accurate(ops):
+    """csrc/common.h tce_erff: the device library's two erf polynomials evaluated branch-free (both + select) with a single
+    v_exp_f32: GELU through an identity GEMM (exact products) against torch's fp64 GELU on a dense grid incl. the |x| = 1 seam of
+    the two paths (x / sqrt(2) = +-1), large |x| and tiny values."""
+    n = 64
+    xs = torch.cat([torch.linspace(-8, 8, 40000), torch.linspace(-1.5, -1.3, 4000), torch.linspace(1.3, 1.5, 4000),
+                    torch.tensor([0.0, 1e-6, -1e-6, 1e-3, 30.0, -30.0])])
+    xs = torch.cat([xs, torch.zeros((-len(xs)) % n)]).view(-1, n)
+    eye = torch.eye(n)
+    ops.set_gemm_mode("f32")   # exact fp32 products: out = GELU(x) up to the kernel's GELU alone
+    try:
+        out = ops.gemm_ex(dev(xs), dev(eye), torch.empty(xs.shape[0], n, device="cuda"), xs.shape[0], n, n, n, n, n, act=ops.ACT_GELU).cpu()
+    finally:
+        ops.set_gemm_mode("f16x3")
+    ref = F.gelu(xs.double())
+    err = (out.double() - ref).abs()
+    # |GELU error| = |x| / 2 * |erf error|: one or two ulps of erf (1.2e-7) at |x| <= 8; as with any fp32 erf-form GELU the far left
+    # tail (1 + erf -> 0) is accurate absolutely, not relatively
+    assert float(err.max()) < 6e-7, float(err.max())
+    core = xs.abs() <= 3
+    assert float((err[core] / ref[core].abs().clamp_min(1e-2)).max()) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(32, 2304, 768), (32, 768, 3072), (7, 768, 768), (100, 3072, 768), (1, 32, 256)])
 def test_thin_linear_weight_stream(ops, M, N, K):
     """csrc/thin.hip: the partial planes of x W^T, finished by tce_splitk_reduce_f32 (bias / GELU / residual / LayerNorm) or
