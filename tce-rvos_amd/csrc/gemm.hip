@@ -242,6 +242,9 @@ static int select_tile_ex(int M, int N, int K, int batch, int conv) {
     if (!conv && ((n256 >= 384 && N >= 512) || (n256 >= 128 && K >= 1024) || (n256 >= 160 && N >= 1024 && K >= 384))) return 256128;
     if (conv && n128 >= 256) return 128128;
     if (n12864 >= 384 && M > 64) return 12864;
+    // deep K with a moderate grid (Swin stage 3's fc2, 4600 x 384 x 1536: 216 tiles of 128x64): the wider tile halves the
+    // operand conversions per MFMA over 48 K slices -- 33.7 vs 39.3 us (tools/gemm_shape_bench.py, ALL_TILES=1)
+    if (n12864 >= 192 && K >= 1024 && M > 64) return 12864;
     return 6464;
   }
   if (n128 >= 512 && N > 64) return 128128;

@@ -34,9 +34,12 @@ def time_shape(M, N, K, tile):
     return e0.elapsed_time(e1) / 100 * 1e3
 
 
+if os.environ.get("BENCH_GEMM_MODE"):  # f16: single-pass arithmetic (how much of a shape's time is MFMA / split work?)
+    ops.set_gemm_mode(os.environ["BENCH_GEMM_MODE"])
 _r = ops.routes(ops.Routes())  # nothing registered: the tiled GEMM
 _r.__enter__()
 for M, N, K in shapes:
+    lib().tce_gemm_force_tile(0)  # (a forced tile of the previous shape would be echoed back)
     sel = lib().tce_gemm_select_tile_ex(M, N, K, 1, 0)
     res = {t: time_shape(M, N, K, t) for t in TILES}
     print(f"{M}x{N}x{K}: selected {sel}: " + "  ".join(f"{'auto' if t == 0 else t}: {us:6.1f} us" for t, us in res.items()) +

@@ -23,10 +23,10 @@ log = []
 orig = ops._gemm_launch
 
 
-def logged(g, splitk=1, ws=None):
+def logged(g, splitk=1, ws=None, *rest, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    orig(g, splitk, ws)
+    orig(g, splitk, ws, *rest, **kw)
     e1.record()
     stage = pipeline.STAGE_EVENTS[-1][0] if pipeline.STAGE_EVENTS else "?"
     log.append((stage, g.M, g.N, g.K, max(1, g.batch), int(g.conv), splitk, torch.cuda.current_stream().cuda_stream, e0, e1))
