@@ -1179,7 +1179,9 @@ def test_ffn_fused_cold_operands(ops, M, C, Hd, act):
         assert bad == 0, f"launch {rep}: {bad} of {M} rows wrong (max err {err.nan_to_num(1e30).max().item():.3e})"
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(72000, 256, 256, "ln_out"), (72000, 384, 256, "plain"), (72000, 288, 96, "ln_in")])
+@pytest.mark.parametrize("M,N,K,variant", [(72000, 256, 256, "ln_out"), (72000, 384, 256, "plain"), (72000, 288, 96, "ln_in"),
+                                           (4600, 1152, 384, "ln_in"), (7680, 384, 384, "plain"),     # round 4: K = 384 (Swin-T stage 3)
+                                           (16200, 512, 512, "plain"), (16200, 1536, 512, "ln_in")])  # and K = 512 (Swin-B stage 3)
 def test_rowlin_cold_operands(ops, M, N, K, variant):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).cuda()
