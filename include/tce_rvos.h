@@ -112,6 +112,8 @@ int tce_patch_embed_f32(const float* frames, const float* w, const float* b, con
 /* Swin (shifted-)window attention core over tokens [T, H, W]: reads packed qkv [T*H*W, 3C] (q|k|v, heads of 32),
  * applies zero-pad-to-x7 (padded tokens carry qkv = bias), cyclic shift, 7x7 windows, q*scale, relative position
  * bias table[169, nH], the -100 shift mask, softmax, AV; writes out [T*H*W, C] in un-shifted token order.
+ * Arithmetic: exact-fp32 matrix-core kernel in mode 0; in the split-fp16 / single-pass modes the window runs as the (1,7,7) form
+ * of tce_window_attn3d_f32's kernel (fp32-class results, see tce_set_gemm_mode).
  * Reference: swin_transformer.py:50-77,127-158,214-249,370-388. */
 int tce_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias_table, float* out, int32_t T,
                         int32_t H, int32_t W, int32_t C, int32_t nH, int32_t shift, tceStream stream);
