@@ -653,6 +653,8 @@ class ReferFormer(nn.Module):
             raise ValueError("clip groups: token ids [G, L], G <= 64")
         size = targets[0]["size"]
         img_h, img_w = float(size[0]), float(size[1])
+        if any((float(t["size"][0]), float(t["size"][1])) != (img_h, img_w) for t in targets[1:]):
+            raise ValueError("clip groups: the clips of a group share one target size")
         self._ensure_packed()
         ops.range_poll(clips[0].device)
         Tc = shp[0]
