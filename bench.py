@@ -39,8 +39,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_traffic.json")
-PMC_FALLBACK = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r03_pmc_traffic.json")
 LATENCY_SUMMARY = os.path.join("profiles", "r04_latency_bound.json")
 
 
