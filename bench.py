@@ -106,8 +106,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the value_f32_exact / value_text_cached passes")
     ap.add_argument("--gemm-mode", default="f16x3", choices=["f32", "f16x3", "f16"],
                     help="f16x3 (default): fp32-accurate 3 x fp16 split; f32: exact fp32 MFMA; f16: one fp16 MFMA per product (config 5)")
-    from tce_rvos_amd.model import ARITH_POLICIES  # (imports torch; touches no GPU)
-    ap.add_argument("--arith-policy", default="uniform", choices=sorted(ARITH_POLICIES),
+    ap.add_argument("--arith-policy", default="uniform",  # validated against model.ARITH_POLICIES after _ensure_built()
                     help="per-site arithmetic (tce_rvos_amd.model.ARITH_POLICIES): 'uniform' = --gemm-mode everywhere; "
                          "'cfg5_mixed' = single-pass fp16 in the site groups the committed sensitivity table allows")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -162,6 +161,9 @@ def main():
 
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks_async
+    from tce_rvos_amd.model import ARITH_POLICIES
+    if args.arith_policy not in ARITH_POLICIES:
+        raise SystemExit(f"--arith-policy: unknown policy {args.arith_policy!r}; choose from {sorted(ARITH_POLICIES)}")
 
     margs = argparse.Namespace(backbone=args.backbone, with_box_refine=True, binary=True, freeze_text_encoder=True,
                                f_token=8, qtrans=True, num_feature_levels=4)
@@ -260,6 +262,37 @@ def main():
         elapsed = float(tmax.item())
     ops.check_range(dev)  # split-fp16 range guard: a tripped flag invalidates the number
 
+    def max_over_ranks(sec):
+        if not dist_on:
+            return sec
+        t = torch.tensor([sec], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dist_variants = {}
+    if dist_on and Gp > 1 and rank == 0:
+        # BASELINE config 4's per-rank shape is a clip GROUP (64 clips over 8 GPUs = 8 per rank): the first clip of rank 0's group
+        # must be what its own B = 1 forward gives (forward_group's contract; another kernel route at the group's row count is
+        # allowed: 2e-5 of the tensor's range)
+        k0 = 0
+        grp = model.forward_group([clips[(k0 + j) % n_pool] for j in range(Gp)], ids_groups[k0], targets)
+        solo_out = model([clips[k0 % n_pool]], ids[k0 % n_pool], targets)
+        torch.cuda.synchronize()
+        rel = {k: float((grp[0][k] - solo_out[k]).abs().max() / solo_out[k].abs().max().clamp_min(1e-30))
+               for k in ("pred_logits", "pred_boxes", "pred_masks")}
+        dist_variants["group_first_clip_vs_b1_max_rel_err"] = rel
+        if max(rel.values()) > 2e-5:
+            raise SystemExit(f"bench.py: the group's first clip differs from its B = 1 forward: {rel}")
+    if dist_on and world > 1 and Gp == 1 and C == 1 and model.use_graph and args.gemm_mode != "f32" and not args.no_variants:
+        # N > 1 lines also carry the rate at config 4's per-rank shape (8 clips per rank as ONE launch program), gather included;
+        # every rank runs it (the step holds the collective)
+        Gp = 8
+        ids_groups = [torch.cat([ids[(k + j) % n_pool] for j in range(Gp)], 0) for k in range(n_pool)]
+        n_var = max(6, min(args.steps, 30))
+        t_g8 = max_over_ranks(timed(n_var, 3))
+        dist_variants["value_group8"] = round(n_var * world * Gp / t_g8, 3)
+        Gp = 1
+
     roofline, roofline_hbm = None, None
     C_saved, C = C, 1  # the instrumented pass, the variants and the parity check run one clip at a time
     Gp_saved, Gp = Gp, 1
@@ -349,6 +382,7 @@ def main():
             roofline_hbm["other_hbm_bound_kernels"] = others
 
     variants = {}
+    exact_masks, product_err = None, {}
     if solo and not args.no_variants:
         n_var = max(10, min(args.steps, 60))
         if model.use_graph and C_saved == 1:
@@ -370,8 +404,20 @@ def main():
             ops.set_gemm_mode("f32")
             model.repack()  # captured graphs hold the split-mode kernels
             variants["value_f32_exact"] = round(n_var / timed(n_var, 6, gather=False), 3)
+            exact_masks = step(0, gather=False)["pred_masks"].cpu()  # the exact-fp32 pass's own result, for the parity leg
             ops.set_gemm_mode(args.gemm_mode)
             model.repack()
+            # per-product error of both arithmetics, measured here: one 512 x 512 x 1024 GEMM with four decades of dynamic range
+            # along K against fp64, as max |c - ref| / sum_k |a||b|  (tests/test_kernels_gpu.py::test_gemm_split_fp16_is_fp32_accurate)
+            gq = torch.Generator().manual_seed(11)
+            qa = torch.randn(512, 1024, generator=gq) * torch.logspace(-2, 2, 1024)[None, :]
+            qw = torch.randn(512, 1024, generator=gq) / 32.0
+            qref, qscale = qa.double() @ qw.double().T, qa.double().abs() @ qw.double().abs().T
+            for qm in ("f32", args.gemm_mode):
+                ops.set_gemm_mode(qm)
+                qo = ops.gemm(qa.to(dev), qw.to(dev)).cpu().double()
+                product_err[qm] = float(((qo - qref).abs() / qscale).max())
+            ops.set_gemm_mode(args.gemm_mode)
 
     cpu_baseline, parity = None, None
     if solo and not args.no_cpu_baseline:
@@ -415,6 +461,10 @@ def main():
                   "max_abs_logit_err": err, "max_rel_logit_err": err / float(ref["pred_masks"].abs().max()),
                   # pixels where a sign flip is numerically meaningless
                   "frac_pixels_abs_logit_lt_1e-3": float((ref["pred_masks"].abs() < 1e-3).float().mean())}
+        if exact_masks is not None:  # the exact-fp32 pass (every product on v_mfma_f32_32x32x2_f32) against the same oracle output
+            e_err = float((exact_masks - ref["pred_masks"]).abs().max())
+            parity["f32_exact"] = {"mask_iou_vs_oracle": round(O.mask_iou(exact_masks > 0, ref["pred_masks"] > 0), 6),
+                                   "max_abs_logit_err": e_err, "max_rel_logit_err": e_err / float(ref["pred_masks"].abs().max())}
 
     if parity is not None and not parity["criterion_met"]:
         print(f"bench.py: PARITY FAILURE: mask IoU vs the oracle {parity['mask_iou_vs_oracle']} misses the 1e-3 criterion in this "
@@ -449,7 +499,31 @@ def main():
                 "valid": None if parity is None else parity["criterion_met"],
                 "latency_bound": _latency_summary(cfg_name),
                 "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity}
+        if roofline is not None and "value_f32_exact" in variants:
+            # The precision story in one place.  The headline arithmetic is NOT the reference's fp32 FMA chain: it is
+            # fp32-CLASS (each operand = two RTZ fp16 halves, three fp16 MFMAs per product, lo*lo dropped, fp32 accumulate).
+            # What that costs per product and end to end is measured by this run, next to the same clip on the exact fp32 MFMA.
+            ex = variants["value_f32_exact"]
+            flop_per_clip = 1.19e12  # SURVEY 8d (config 2; other configurations: not restated, frac fields omitted)
+            prec = {"headline_arithmetic": args.gemm_mode, "value": line["value"], "value_f32_exact": ex,
+                    "ms_per_step_f32_exact": round(1e3 / ex, 3),
+                    "per_product_err_over_sum_abs": {k: float(f"{v:.3e}") for k, v in product_err.items()},
+                    "per_product_err_ratio_vs_f32": (round(product_err[args.gemm_mode] / product_err["f32"], 2)
+                                                     if product_err.get("f32") else None),
+                    "max_rel_logit_err": None if parity is None else {args.gemm_mode: parity["max_rel_logit_err"],
+                                                                      "f32": parity.get("f32_exact", {}).get("max_rel_logit_err")},
+                    "note": "f32 pass: every matrix product on v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains), tiled GEMM "
+                            "kernels only (the fused FFN / cross-attention / Swin / convolution kernels exist in the split arithmetic)"}
+            if cfg_name == "BASELINE config 2":
+                prec["whole_clip_tflops"] = {args.gemm_mode: round(flop_per_clip / (elapsed / clips_total) / 1e12, 1),
+                                             "f32": round(flop_per_clip * ex / 1e12, 1)}
+                n_pass = {"f32": 1, "f16x3": 3, "f16": 1}[args.gemm_mode]  # MFMAs issued per algorithmic product
+                prec["whole_clip_frac"] = {"of_fp16_dense_2500_issued": round(n_pass * flop_per_clip / (elapsed / clips_total) / 2.5e15, 4),
+                                           "of_fp16_dense_2500_algorithmic": round(flop_per_clip / (elapsed / clips_total) / 2.5e15, 4),
+                                           "f32_exact_of_fp32_matrix_157.3": round(flop_per_clip * ex / 157.3e12, 4)}
+            roofline["precision"] = prec
         line.update(variants)
+        line.update(dist_variants)
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()  # rank 0's extra (collective-free) passes are done: leave together

@@ -626,12 +626,8 @@ def encoder(sd, cfg, src, shapes, valid_ratios, pos, padding_mask, pre="transfor
         bus_pos = sd[pre + "memory_pos"][None].repeat(N, 1, 1)
     for i in range(cfg.enc_layers):
         lp = f"{pre}layers.{i}."
-        if cfg.f_token > 0:
-            out, bus = frame_token_layer(sd, lp + "ftoken_layers.", cfg, out, pos, bus, bus_pos, shapes,
-                                         padding_mask, valid_ratios)
-        s2, _, _ = msda_module(sd, lp + "self_attn.", out + pos, ref, out, shapes, padding_mask, M, L, P)
-        out = _ln(sd, lp + "norm1", out + s2)
-        out = _ln(sd, lp + "norm2", out + _ffn(sd, lp, out))
+        out, bus = encoder_layer(sd, lp, cfg, out, pos, ref, shapes, valid_ratios, padding_mask,
+                                 bus if cfg.f_token > 0 else None, bus_pos if cfg.f_token > 0 else None)
     return out
 
 
@@ -641,6 +637,34 @@ def _mlp(sd, pre, x, n):
         if i < n - 1:
             x = F.relu(x)
     return x
+
+
+def decoder_layer(sd, lp, cfg, out, query_pos, ref_in, memory, shapes, padding_mask):
+    """DeformableTransformerDecoderLayer.forward tce_deformable_transformer.py:675-699 (IQT branch :683).  out, query_pos
+    [B*T, Q, C]; ref_in [B*T, Q, L, 2 or 4] (already scaled by the valid ratios).  Returns (out, sampling locations, weights)."""
+    M, L, P = cfg.nheads, cfg.num_feature_levels, cfg.dec_n_points
+    q = out + query_pos
+    if cfg.qtrans:
+        # [B*T, Q, C] fed seq-first untransposed: sequence axis = frames, batch axis = query slots
+        t2 = _mha_sd(sd, lp + "self_attn.", q, q, out, M)
+    else:
+        t2 = _mha_sd(sd, lp + "self_attn.", q.transpose(0, 1), q.transpose(0, 1), out.transpose(0, 1), M).transpose(0, 1)
+    out = _ln(sd, lp + "norm2", out + t2)
+    t2, loc, aw = msda_module(sd, lp + "cross_attn.", out + query_pos, ref_in, memory, shapes, padding_mask, M, L, P)
+    out = _ln(sd, lp + "norm1", out + t2)
+    out = _ln(sd, lp + "norm3", out + _ffn(sd, lp, out))
+    return out, loc, aw
+
+
+def encoder_layer(sd, lp, cfg, out, pos, ref, shapes, valid_ratios, padding_mask, bus=None, bus_pos=None):
+    """DeformableTransformerEncoderLayer.forward :535-553: frame-token layer (f_token > 0) -> MSDA self-attention -> FFN."""
+    M, L, P = cfg.nheads, cfg.num_feature_levels, cfg.enc_n_points
+    if cfg.f_token > 0:
+        out, bus = frame_token_layer(sd, lp + "ftoken_layers.", cfg, out, pos, bus, bus_pos, shapes, padding_mask, valid_ratios)
+    s2, _, _ = msda_module(sd, lp + "self_attn.", out + pos, ref, out, shapes, padding_mask, M, L, P)
+    out = _ln(sd, lp + "norm1", out + s2)
+    out = _ln(sd, lp + "norm2", out + _ffn(sd, lp, out))
+    return out, bus
 
 
 def decoder(sd, cfg, tgt, ref, memory, shapes, valid_ratios, query_pos, padding_mask, pre="transformer.decoder."):
@@ -654,16 +678,7 @@ def decoder(sd, cfg, tgt, ref, memory, shapes, valid_ratios, query_pos, padding_
             ref_in = ref[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         else:
             ref_in = ref[:, :, None] * valid_ratios[:, None]
-        q = out + query_pos
-        if cfg.qtrans:
-            # [B*T, Q, C] fed seq-first untransposed: sequence axis = frames, batch axis = query slots
-            t2 = _mha_sd(sd, lp + "self_attn.", q, q, out, M)
-        else:
-            t2 = _mha_sd(sd, lp + "self_attn.", q.transpose(0, 1), q.transpose(0, 1), out.transpose(0, 1), M).transpose(0, 1)
-        out = _ln(sd, lp + "norm2", out + t2)
-        t2, loc, aw = msda_module(sd, lp + "cross_attn.", out + query_pos, ref_in, memory, shapes, padding_mask, M, L, P)
-        out = _ln(sd, lp + "norm1", out + t2)
-        out = _ln(sd, lp + "norm3", out + _ffn(sd, lp, out))
+        out, loc, aw = decoder_layer(sd, lp, cfg, out, query_pos, ref_in, memory, shapes, padding_mask)
         # top-30 sample bookkeeping :752-758
         N, Lq = loc.shape[:2]
         loc_n = loc / valid_ratios[:, None, None, :, None, :]
@@ -855,8 +870,10 @@ def fusion(sd, tgt, text, text_mask, text_pos, pre="fusion_module.multihead_attn
 
 def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidden: Tensor, text_pooled: Tensor,
             text_attn_mask: Optional[Tensor] = None, img_size: Optional[Tuple[int, int]] = None,
-            pad_mask: Optional[Tensor] = None, return_stages: bool = False):
+            pad_mask: Optional[Tensor] = None, return_stages: bool = False, valid_index: Optional[int] = None):
     """One clip.  frames [T,3,H,W]; text_hidden [1,L,768]; text_pooled [1,768]; text_attn_mask [1,L] (1 = token).
+    valid_index: targets[0]['valid_indices'] of the A2D / JHMDB single-frame path (tce_rvos.py:233-243): the backbone sees
+    all T frames, everything after it only frame `valid_index` (t -> 1).
     Returns the reference's output dict (B = 1)."""
     sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items() if not k.startswith("text_encoder.")}
     T, _, H, W = frames.shape
@@ -880,6 +897,13 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidde
     feat_masks = [interp_nearest(pad_mask[None].float(), f.shape[-2:]).bool()[0] for f in feats]
     poses = [pos_sine_2d(m, cfg.hidden_dim // 2) for m in feat_masks]
     stages["backbone"] = feats
+    if valid_index is not None:  # tce_rvos.py:233-243: index_select of features, masks, position maps and samples.mask; t -> 1
+        vi = int(valid_index)
+        feats = [f[vi:vi + 1] for f in feats]
+        feat_masks = [m[vi:vi + 1] for m in feat_masks]
+        poses = [p[vi:vi + 1] for p in poses]
+        pad_mask = pad_mask[vi:vi + 1]
+        t = 1
 
     # text  (forward_text :406-424)
     text_mask = text_attn_mask.ne(1).bool()

@@ -252,6 +252,7 @@ class ReferFormer(nn.Module):
         self._stamp = None      # (process mode, policy) the packed operands and the captured graphs were built for
         self._routes = ops.Routes()
         self._nograph = set()   # keys whose capture ran out of arena: they stay on the eager path
+        self._group_checked = set()  # forward_group keys whose token ids were checked for the pad id
 
     # ---------------------------------------------------------------- parameter tree
     def _node_for(self, key):
@@ -301,6 +302,7 @@ class ReferFormer(nn.Module):
         if getattr(self, "_routes", None) is not None:
             self._routes.clear()
         self._nograph = set()
+        self._group_checked = set()
 
     # ---------------------------------------------------------------- per-site arithmetic
     def set_arith_policy(self, policy):
@@ -582,8 +584,10 @@ class ReferFormer(nn.Module):
         if b != 1 or vids.shape[0] != 1:
             raise NotImplementedError("one clip per forward (B = 1): the reference mixes clips inside a batch "
                                       "(FTF token attention, IQT) so batching changes results; shard clips instead")
-        if "valid_indices" in targets[0]:
-            raise NotImplementedError("valid_indices (A2D/JHMDB single-frame path) is outside the hot path")
+        # A2D / JHMDB: one annotated frame per clip (tce_rvos.py:233-243): everything after the backbone runs on that frame
+        select = int(targets[0]["valid_indices"]) if "valid_indices" in targets[0] else None
+        if select is not None and not 0 <= select < vids.shape[1]:
+            raise IndexError(f"valid_indices {select} outside the clip's {vids.shape[1]} frames")
         if not vids.is_cuda:
             raise RuntimeError("inputs must be on the GPU: this path has no CPU implementation")
         frames = vids[0].to(torch.float32).contiguous()
@@ -595,12 +599,13 @@ class ReferFormer(nn.Module):
         ops.range_poll(frames.device)  # split-fp16 range guard: a tripped flag of an EARLIER forward raises here
         cached = self._text_lookup(ids, ids_host, frames.device)
         if cached is not None:  # text features of this expression are cached: the clip runs from them
-            out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot, valid_hw=valid)
+            out = self.forward_features(frames, cached[0], cached[1], img_h, img_w, slot=slot, valid_hw=valid, select=select)
         else:
             ids = ids.to(frames.device)
-            key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp, valid)
+            key = ("clip", tuple(frames.shape), tuple(ids.shape), img_h, img_w, self.training, int(slot), self._stamp, valid, select)
             if not self._want_graph(key):
-                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, valid=valid)
+                out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, valid=valid,
+                                select=select)
             else:
                 # one hipGraph per input shape: RoBERTa runs as a parallel branch beside the backbone, the decoder
                 # beside the pixel decoder
@@ -611,10 +616,11 @@ class ReferFormer(nn.Module):
                     def text_fn(alloc):
                         return self._text_plan().forward(st[1], alloc)
 
-                    ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, valid=valid), frames, slot)
+                    ent = self._capture(key, st, lambda res: self._run(st[0], text_fn, img_h, img_w, res, valid=valid, select=select),
+                                        frames, slot)
                 if ent is None:  # the capture's arenas did not fit this shape's fallback kernels: eager from now on
                     out = self._run(frames, lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot,
-                                    valid=valid)
+                                    valid=valid, select=select)
                 else:
                     out = self._replay(key, ent, (frames, ids))
         ops.range_snapshot_async(frames.device)
@@ -631,7 +637,8 @@ class ReferFormer(nn.Module):
         across a clip's frames or at its caption are block-diagonal per clip (pipeline._run_clip) -- unlike the reference's own
         batch dimension, which mixes the clips of a batch.  Why: a clip alone leaves the GPU latency-bound for a third
         of its time (Swin stages 3-4 at 4600 rows, the text branch, the token / decoder paths); G clips share those launches:
-        DESIGN section 3.10 has the measured clips/s.  Video-Swin's 3-D windows span a clip's frames: its window kernel is launched
+        DESIGN section 3.10 has the measured clips/s.  Every position of `captions` [G, L] is a token: rows padded to a common
+        length are INVALID input (rejected on the first sighting of a group shape).  Video-Swin's 3-D windows span a clip's frames: its window kernel is launched
         per clip, everything else is shared.  When `clips` holds the SAME tensor G times (G expressions of one video, the inner loop
         of inference_ytvos.py) the backbone runs once for the group.  Limits: one clip shape and one caption length per group, un-padded clips, G <= 64 (the
         text layers leave the weight-stream kernels for the tiled GEMMs above 128 caption tokens in all)."""
@@ -672,6 +679,15 @@ class ReferFormer(nn.Module):
             return self._run(frames_now(), lambda alloc: self._text_plan().forward(ids, alloc), img_h, img_w, None, slot, groups=G,
                              shared=shared)
 
+        if key not in self._group_checked:
+            self._group_checked.add(key)
+            # a [G, L] id tensor built by PADDING G captions to one length would silently differ from each clip's B = 1 forward
+            # (the text kernels take every position as a token; the reference masks pads through attention_mask /
+            # key_padding_mask): checked ONCE per group shape, on its first sighting (a device read-back)
+            pad_id = int(getattr(getattr(self.text_encoder, "config", None), "pad_token_id", 1) or 1)
+            if bool((ids == pad_id).any()):
+                raise ValueError(f"clip groups: token ids contain the pad id ({pad_id}): padded captions are not supported -- "
+                                 f"group captions of equal token length (every position of [G, L] is taken as a token)")
         if not self._want_graph(key):
             out = eager()
         else:
@@ -814,15 +830,15 @@ class ReferFormer(nn.Module):
         enc = self.text_encoder(input_ids=ids, attention_mask=att)
         return enc.last_hidden_state.float(), enc.pooler_output.float()
 
-    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None, groups=1, shared=False):
+    def _run(self, frames, text, img_h, img_w, res, slot=0, valid=None, groups=1, shared=False, select=None):
         from .pipeline import run_clip
         T, _, H0, W0 = frames.shape
         if res is None:  # eager: the slot's arena, single stream
             return run_clip(self, frames, text, img_h, img_w, self._get_arena(T * (groups if shared else 1), H0, W0, frames.device, slot),
-                            valid=valid, groups=groups, shared=shared)
+                            valid=valid, groups=groups, shared=shared, select=select)
         arena, side_arena, side_stream, arena2, stream2, arena3, stream3, arena4, stream4 = res
         return run_clip(self, frames, text, img_h, img_w, arena, side_arena, side_stream, clone_outputs=False, valid=valid,
-                        groups=groups, shared=shared,
+                        groups=groups, shared=shared, select=select,
                         fork2=(arena2, stream2) if os.environ.get("TCE_FORK2", "1") != "0" else None,
                         fork3=((arena3, stream3), (arena4, stream4)) if os.environ.get("TCE_FORK3", "1") != "0" else None)
 
@@ -947,26 +963,30 @@ class ReferFormer(nn.Module):
         return hid[None], pooled[None]
 
     @torch.no_grad()
-    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w, slot=0, valid_hw=None):
+    def forward_features(self, frames, text_hidden, text_pooled, img_h, img_w, slot=0, valid_hw=None, select=None):
         """Everything after the text encoder.  frames [T,3,H,W]; text_hidden [L,768]; text_pooled [768].  valid_hw = (rows,
-        columns) of the frames that are not padding (a clip zero-padded at the bottom / right; None: un-padded)."""
+        columns) of the frames that are not padding (a clip zero-padded at the bottom / right; None: un-padded).  select: the
+        annotated frame of the single-frame path (targets[0]['valid_indices'], tce_rvos.py:233-243; None: every frame)."""
         if valid_hw is not None:
             valid_hw = (int(valid_hw[0]), int(valid_hw[1]))
             if valid_hw == (int(frames.shape[-2]), int(frames.shape[-1])):
                 valid_hw = None
         self._ensure_packed()
         text_hidden, text_pooled = text_hidden.contiguous(), text_pooled.contiguous()
+        select = None if select is None else int(select)
         key = ("feat", tuple(frames.shape), int(text_hidden.shape[0]), float(img_h), float(img_w), self.training, int(slot),
-               self._stamp, valid_hw)
+               self._stamp, valid_hw, select)
         if not self._want_graph(key):
-            return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw))
+            return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw,
+                                                   select=select))
         ent = self._graphs.get(key)
         if ent is None:
             st = (frames.clone(), text_hidden.clone(), text_pooled.clone())
-            ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res, valid=valid_hw), frames,
-                                slot)
+            ent = self._capture(key, st, lambda res: self._run(st[0], (st[1], st[2]), img_h, img_w, res, valid=valid_hw, select=select),
+                                frames, slot)
             if ent is None:
-                return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw))
+                return self._tag_diagnostics(self._run(frames, (text_hidden, text_pooled), img_h, img_w, None, slot, valid=valid_hw,
+                                                       select=select))
         return self._tag_diagnostics(self._replay(key, ent, (frames, text_hidden, text_pooled)))
 
 

@@ -451,8 +451,18 @@ def swin_attn_fused(x, pk, qkv_bias, proj_bias, table, g1, b1, T, H, W, Cn, shif
     return out
 
 
-if os.environ.get("TCE_MHA_SPLIT", "1") == "0":  # A/B: every attention launch on the exact fp32-MFMA kernel
-    lib().tce_debug_mha_set_split(0)
+_MHA_SPLIT_OFF = os.environ.get("TCE_MHA_SPLIT", "1") == "0"  # A/B: every attention launch on the exact fp32-MFMA kernel
+_mha_split_applied = False
+
+
+def _apply_mha_split():
+    """The A/B switch is applied at the first attention launch, not at import: importing the package must not load (or
+    require) the HIP library -- bench.py builds it on a fresh checkout AFTER importing the package."""
+    global _mha_split_applied
+    if not _mha_split_applied:
+        _mha_split_applied = True
+        if _MHA_SPLIT_OFF:
+            lib().tce_debug_mha_set_split(0)
 
 
 MHA_WS_MIN_KEYS = int(os.environ.get("TCE_MHA_WS_MIN_KEYS", 1024))
@@ -464,6 +474,7 @@ def mha_core(q, k, v, batch, nheads, Lq, Lk, ldq, ldk, ldv, sQ, sK, sV, out, ldo
     whose fp16 planes of K / V come from it."""
     if scale is None:
         scale = 32 ** -0.5
+    _apply_mha_split()
     if alloc is not None and Lk >= MHA_WS_MIN_KEYS and get_gemm_mode() != "f32":
         ws = alloc(lib().tce_mha_ws_bytes(batch, nheads, Lk) // 4)
         check(lib().tce_mha_ws_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), batch, nheads, Lq, Lk,
@@ -1133,7 +1144,10 @@ def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_m
 # decoder's per-query projections, the text-side key / value projections -- a few dozen rows, exact fp32, up to three
 # projections of the same rows per launch.
 # ---------------------------------------------------------------------------------------------------------------
-FEWROW_MAX_ROWS = int(os.environ.get("TCE_FEWROW_MAX_ROWS", 256))
+# Routed by ROWS: the kernel re-stages its <= 32 x K row block once per 8 output columns, so above ~128 rows it does
+# GEMM-sized work on the VALU (clip groups: 320 token rows, 800 controller rows at G = 8 -- 56 us per launch on average in
+# profiles/r04_kernel_stats_cfg2_group8.csv); those sites take the tiled / split-K GEMM path again.
+FEWROW_MAX_ROWS = int(os.environ.get("TCE_FEWROW_MAX_ROWS", 128))
 FR_NONE, FR_RELU, FR_SIGMOID, FR_GELU = 0, 1, 2, 3
 
 

@@ -64,6 +64,8 @@ if ABLATE or TAPS:
                   RuntimeWarning, stacklevel=2)
 
 
+_TAP_FN = None  # TCE_TAPS diagnostic: the current clip's tap(name, tensor), set by _run_clip
+
 # Diagnostic: when set to a list, run_clip appends (stage name, event recorded on the main stream at the END of the
 # stage) -- tools/stage_times.py (eager mode only).
 STAGE_EVENTS = None
@@ -109,16 +111,16 @@ class _Fork:
 
 
 def run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-             fork3=None, valid=None, groups=1, shared=False):
+             fork3=None, valid=None, groups=1, shared=False, select=None):
     """The clip's launch program with the model's own packed-weight routes active (ops.Routes).  valid = (rows, columns) of
-    the frames that are not padding (None: un-padded clip)."""
+    the frames that are not padding (None: un-padded clip).  select = targets[0]['valid_indices'] (tce_rvos.py:233-243)."""
     with ops.routes(model._routes):
         return _run_clip(model, frames, text, img_h, img_w, ar, side_arena, side_stream, clone_outputs, fork2, fork3, valid, groups,
-                         shared)
+                         shared, select)
 
 
 def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_stream=None, clone_outputs=True, fork2=None,
-              fork3=None, valid=None, groups=1, shared=False):
+              fork3=None, valid=None, groups=1, shared=False, select=None):
     """text: (last_hidden_state [L,768], pooler_output [768]) or a callable(alloc) returning them (the RoBERTa
     forward, run as a parallel branch beside the backbone when a side stream is given).
     side_arena / side_stream: the decoder (~100 latency-bound launches on 25 rows) runs as a parallel branch
@@ -142,6 +144,14 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     T = Tb * G if shared else Tb
     if T % G:
         raise ValueError("clip group: frames must hold `groups` clips of equal length")
+    # select (the A2D / JHMDB single-frame path, tce_rvos.py:233-243): the backbone sees the clip's Tb frames (Video-Swin's
+    # windows span them), every stage after it only frame `select` -- the reference index_selects the features, their masks and
+    # position maps (frame independent here: same padding in every frame) and continues with t = 1
+    if select is not None:
+        if G != 1 or not 0 <= int(select) < Tb:
+            raise ValueError("valid_indices: one clip per forward, index inside the clip")
+        select = int(select)
+        T = 1
     Tc = T // G
     ar.reset()
     if side_arena is not None:
@@ -316,9 +326,17 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         for arx, _ in fork3:
             arx.reset()
 
+    def pick(feat, i):
+        """the selected frame's rows of stage i's map (valid_indices), else the map"""
+        if select is None:
+            return feat
+        hw_i = sizes[i][0] * sizes[i][1]
+        return feat[select * hw_i:(select + 1) * hw_i]
+
     def on_stage(i, feat):
         if i == 0 and text_late:
             text_stage()
+        feat = pick(feat, i)
         if early:
             if i in (1, 2):
                     arx, stx = fork3[i - 1]
@@ -332,6 +350,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             feats = _resnet_backbone(model, frames, ar, sizes, rep=G if shared else 1)
     else:
         feats = _swin_backbone(model, frames, ar, sizes, on_stage, 1 if shared else G, rep=G if shared else 1)
+    feats = [pick(f, i) for i, f in enumerate(feats)]
 
     _stage("backbone")
     text_fork.join()
@@ -454,7 +473,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
 
     taps = {} if TAPS else None  # bisect aid: copies of intermediates ride out with the outputs
 
-    tap_pool = A(cfg.enc_layers * (16 * T * max(Fk, 1) * D + 3 * T * S * D)) if taps is not None else None  # persistent (base level)
+    tap_pool = A(cfg.enc_layers * (16 * T * max(Fk, 1) * D + 3 * T * S * D) + cfg.dec_layers * T * Q * D +
+                 2 * T * sum(h_ * w_ for h_, w_ in sizes) * D) if taps is not None else None  # persistent (base level)
     tap_off = [0]
 
     def tap(name, t):
@@ -463,6 +483,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             buf = tap_pool[tap_off[0]:tap_off[0] + n]
             tap_off[0] += n
             taps[name] = ops.tile(t.reshape(-1), 1, out=buf).view(t.shape)
+
+    global _TAP_FN  # module-level functions (_lateral) tap through it; diagnostic runs only
+    _TAP_FN = tap if taps is not None else None
 
     for i in range(cfg.enc_layers):
         lp = f"transformer.encoder.layers.{i}."
@@ -662,6 +685,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     dec_fork = _Fork(side_stream if side_arena is not None else None)
     with dec_fork, model.arith("decoder"):
         hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
+        tap("dec.hs", hs)
         # controller MLP + parameter packing of the dynamic mask head (:371-373, 536-559): depend on hs only, so they
         # ride in the decoder branch instead of the main chain's tail
         dA = dar.alloc
@@ -692,11 +716,11 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     # ------------------------------------------------------------------ dynamic mask head (:371-380, 426-510)
     h4, w4 = sizes[0]
     m0 = ar.mark()
-    G = A(T, h4 * w4, nl * Q * 8)
+    gmat = A(T, h4 * w4, nl * Q * 8)  # (not `G`: the closures above read the clip-group count G late-bound)
     with model.arith("mask_head"):
-        ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, G)
+        ops.gemm_batched(mask_feats.view(T, h4 * w4, cfg.mask_dim), w0f, gmat)
     masks = A(nl, T, Q, h4, w4)
-    ops.mask_tail(G, tail, mask_refs, ref_ld, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
+    ops.mask_tail(gmat, tail, mask_refs, ref_ld, masks, nl, T, Q, h4, w4, img_h, img_w, 4)
 
     _stage("mask head (+ decoder join)")
     # ------------------------------------------------------------------ output dict (:360-393); leave the arena
@@ -952,6 +976,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
                          w[bp + "norm2.bias"])
         arx.release(m1)
     ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx, group="pixel.ffn")
+    if _TAP_FN is not None:
+        _TAP_FN(f"vl{stage}", tgt)  # the VisionLanguageBlock's output (segmentation.py:326-377)
     return tgt
 
 

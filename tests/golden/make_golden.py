@@ -26,6 +26,15 @@ Fixtures
   statedict_*.json     the reference's state-dict keys/shapes (the drop-in checkpoint contract); *_plain = without
                        --with_box_refine/--f_token/--qtrans
   harness_cases.npz    caller harness H (inference_ytvos.py:238-250): logits+masks -> thresholded mask
+  e2e_swin_t_valid_idx.npz  the A2D / JHMDB single-frame path: T=3 frames of 72x100 with targets[0]['valid_indices'] = 1
+                       (tce_rvos.py:233-243: everything after the backbone sees that one frame; t -> 1)
+  perop_swin_t.npz, perop_vswin_t.npz, perop_noqtrans.npz  (round 5, SURVEY 8c list (ii)-(vii)) inputs and outputs of the
+                       reference's OWN sub-modules, captured by forward hooks while the reference runs a small clip with the
+                       synthetic weights (weights regenerate from the salt): shifted + padded SwinTransformerBlock and its
+                       WindowAttention (with the -100 mask), PatchMerging at an odd size, VisionLanguageFusionModule,
+                       the four VisionLanguageBlocks (sr 8 / 4 / 2 / 1), FrameTokenLayer, an encoder layer, decoder layers with
+                       2-d and 4-d reference points (qtrans on; perop_noqtrans: off), dynamic_mask_with_coords;
+                       WindowAttention3D at T = 9 (8-frame windows, shifted, masked) and at T = 3 ((3,7,7) windows, [:N,:N] table)
 """
 import os
 import sys
@@ -231,7 +240,126 @@ def gen_round4():
     gen_statedict_manifest(m, "statedict_swin_b.json")
 
 
+def _arr(v):
+    """A hook argument as an array (None and non-numeric values are skipped by the caller)."""
+    if torch.is_tensor(v):
+        return _np(v.to(torch.float32) if v.dtype == torch.bool else v)
+    if isinstance(v, (int, float, bool)):
+        return np.asarray(v)
+    if isinstance(v, (list, tuple)) and v and all(isinstance(x, (int, float)) for x in v):
+        return np.asarray(v)
+    return None
+
+
+def _hook_modules(model, names, fx, first_only=True):
+    """Forward hooks on the named sub-modules of the REFERENCE model: positional inputs -> `<tag>_in<i>`, keyword inputs ->
+    `<tag>_kw_<name>`, the output -> `<tag>_out` (tag = the module path with dots as underscores), first call only."""
+    mods = dict(model.named_modules())
+    handles = []
+    for name in names:
+        tag = name.replace(".", "_")
+
+        def hook(m, args, kwargs, out, tag=tag):
+            if first_only and tag + "_out" in fx:
+                return
+            for i, a in enumerate(args):
+                v = _arr(a)
+                if v is not None:
+                    fx[f"{tag}_in{i}"] = v
+            for k, a in kwargs.items():
+                v = _arr(a)
+                if v is not None:
+                    fx[f"{tag}_kw_{k}"] = v
+            o = out[0] if isinstance(out, (tuple, list)) else out
+            fx[tag + "_out"] = _np(o)
+            for extra in ("H", "W"):  # SwinTransformerBlock carries its grid as attributes set by BasicLayer
+                if hasattr(m, extra) and isinstance(getattr(m, extra), int):
+                    fx[f"{tag}_attr_{extra}"] = np.asarray(getattr(m, extra))
+
+        handles.append(mods[name].register_forward_hook(hook, with_kwargs=True))
+    return handles
+
+
+def gen_perop(name, backbone, T, H, W, seed, modules, extra_args=(), wrap_mask_head=False):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tce_rvos_amd.weights import load_synth_weights
+    args = rh.reference_args(backbone)
+    if extra_args == "noqtrans":
+        args.qtrans = False
+    model = rh.build_reference_model(args, seed=0, roberta_layers=1)
+    load_synth_weights(model, salt=seed)
+    fx = {"thw": np.asarray([T, H, W]), "frames_seed": np.asarray(seed + 1), "weights_salt": np.asarray(seed),
+          "cfg_backbone": np.asarray(backbone)}
+    _hook_modules(model, modules, fx)
+    model.text_encoder.register_forward_hook(  # third-party RoBERTa (random init): its outputs are an INPUT of the path
+        lambda m, i, o: fx.update(text_hidden=_np(o.last_hidden_state), text_pooled=_np(o.pooler_output)))
+    if wrap_mask_head:
+        orig = model.dynamic_mask_with_coords
+
+        def wrapped(mask_features, mask_head_params, reference_points, targets):
+            o = orig(mask_features, mask_head_params, reference_points, targets)
+            if "maskhead_out" not in fx:
+                fx.update(maskhead_in0=_np(mask_features), maskhead_in1=_np(mask_head_params), maskhead_in2=_np(reference_points),
+                          maskhead_size=_np(targets[0]["size"]), maskhead_out=_np(o))
+            return o
+
+        model.dynamic_mask_with_coords = wrapped
+    frames = _synth_inputs(T, H, W, seed + 1)
+    with torch.no_grad():
+        out = model([frames], ["synthetic"], [{"size": torch.tensor((H, W))}])
+    fx["out_pred_masks"] = _np(out["pred_masks"])
+    missing = [m for m in modules if m.replace(".", "_") + "_out" not in fx]
+    assert not missing, missing
+    np.savez_compressed(os.path.join(HERE, name), **fx)
+    print(name, len(fx), "arrays", os.path.getsize(os.path.join(HERE, name)))
+
+
+def gen_valid_idx():
+    """tce_rvos.py:233-243: one annotated frame per clip."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tce_rvos_amd.weights import load_synth_weights
+    T, H, W, seed, vi = 3, 72, 100, 16, 1
+    model = rh.build_reference_model(rh.reference_args("swin_t_p4w7"), seed=0, roberta_layers=1)
+    load_synth_weights(model, salt=seed)
+    cap = {}
+    model.text_encoder.register_forward_hook(
+        lambda m, i, o: cap.update(hid=o.last_hidden_state.detach(), pool=o.pooler_output.detach()))
+    frames = _synth_inputs(T, H, W, seed + 1)
+    with torch.no_grad():
+        out = model([frames], ["synthetic"], [{"size": torch.tensor((H, W)), "valid_indices": torch.tensor(vi)}])
+    fx = {"text_hidden": _np(cap["hid"]), "text_pooled": _np(cap["pool"]), "thw": np.asarray([T, H, W]),
+          "frames_seed": np.asarray(seed + 1), "weights_salt": np.asarray(seed), "valid_index": np.asarray(vi),
+          "cfg_backbone": np.asarray("swin_t_p4w7")}
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points", "memory"):
+        fx["out_" + k] = _np(out[k])
+    for i, a in enumerate(out["aux_outputs"]):
+        for k, v in a.items():
+            fx[f"aux{i}_{k}"] = _np(v)
+    np.savez_compressed(os.path.join(HERE, "e2e_swin_t_valid_idx.npz"), **fx)
+    print("e2e_swin_t_valid_idx.npz pred_masks", tuple(out["pred_masks"].shape))
+
+
+def gen_round5():
+    gen_valid_idx()
+    b = "backbone.0.body."
+    gen_perop("perop_swin_t.npz", "swin_t_p4w7", T=3, H=72, W=100, seed=18, wrap_mask_head=True, modules=[
+        b + "layers.0.blocks.1", b + "layers.0.blocks.1.attn", b + "layers.1.blocks.0", b + "layers.1.downsample",
+        "fusion_module", "pixel_decoder.cross_attn_1", "pixel_decoder.cross_attn_2", "pixel_decoder.cross_attn_3",
+        "pixel_decoder.cross_attn_4", "transformer.encoder.layers.0.ftoken_layers", "transformer.encoder.layers.0",
+        "transformer.decoder.layers.0", "transformer.decoder.layers.1"])
+    gen_perop("perop_noqtrans.npz", "swin_t_p4w7", T=3, H=72, W=100, seed=18, extra_args="noqtrans",
+              modules=["transformer.decoder.layers.0", "transformer.decoder.layers.1"])
+    gen_perop("perop_vswin_t.npz", "video_swin_t_p4w7", T=9, H=72, W=100, seed=20,
+              modules=[b + "layers.0.blocks.1.attn"])
+    gen_perop("perop_vswin_t_short.npz", "video_swin_t_p4w7", T=3, H=72, W=100, seed=20,
+              modules=[b + "layers.0.blocks.1.attn"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round5":
+        torch.set_num_threads(8)
+        gen_round5()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round4":
         torch.set_num_threads(8)
         gen_round4()
@@ -254,4 +382,5 @@ if __name__ == "__main__":
     gen_plain_manifest()
     gen_resnet()
     gen_round4()
+    gen_round5()
     print("done")

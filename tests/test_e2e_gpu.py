@@ -514,6 +514,67 @@ def test_two_rank_gloo_rehearsal_on_one_device(group):
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
 
 
+def test_config4_per_rank_shape_through_the_two_rank_flow():
+    """BASELINE config 4 = 64 config-2 clips over 8 GPUs = EIGHT clips per rank.  That per-rank shape (Swin-T, T = 5, 360 x 640,
+    32 tokens, 8 clips per forward as one launch program) goes through bench.py's N > 1 control flow here with two ranks sharing
+    this box's GPU over gloo: 16 clips per step, every rank finds its own block at its own place in the gathered masks (bench.py
+    exits non-zero otherwise: the gathered order), and rank 0's first clip of a group equals its own B = 1 forward to 2e-5 of
+    the tensor's range.  What stays untested is the hardware only (8 devices, RCCL over xGMI).  Ref: inference_ytvos.py:96-113."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TCE_BENCH_ONE_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--steps", "3", "--warmup", "2", "--group", "8", "--no-cpu-baseline", "--no-roofline",
+                                       "--no-variants"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    line = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
+    assert "BASELINE config 2" in line["config"]["workload"] and line["n_gpus"] == 2
+    assert line["config"]["clips_per_step"] == 16 and line["config"]["clips_per_forward"] == 8 and line["value"] > 0
+    c = line["collective"]
+    assert c["gathered_shape"] == [16, 5, 360, 640] and c["own_block_matches"] and c["world"] == 2
+    assert c["bytes_per_rank_per_step"] == 8 * 5 * 360 * 640
+    rel = line["group_first_clip_vs_b1_max_rel_err"]
+    assert max(rel.values()) <= 2e-5, rel
+
+
+def test_valid_indices_single_frame_path_matches_reference(models):
+    """tce_rvos.py:233-243 (A2D / JHMDB: one annotated frame per clip): the backbone sees the clip's 3 frames, everything after
+    it frame 1 only (t -> 1).  Against the REFERENCE run with targets[0]['valid_indices'] = 1; eager, captured and replayed."""
+    fx = load_npz("e2e_swin_t_valid_idx.npz")
+    T, H, W = (int(v) for v in fx["thw"])
+    vi = int(fx["valid_index"])
+    model = models("swin_t_p4w7", int(fx["weights_salt"]))
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    hid, pooled = torch.from_numpy(fx["text_hidden"])[0].cuda(), torch.from_numpy(fx["text_pooled"])[0].cuda()
+    outs = [model.forward_features(frames, hid, pooled, float(H), float(W), select=vi) for _ in range(3)]  # eager, capture, replay
+    torch.cuda.synchronize()
+    out = outs[0]
+    assert tuple(out["pred_masks"].shape) == (1, 1, 5, 18, 25) and tuple(out["memory"].shape) == tuple(fx["out_memory"].shape)
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("reference_points", 1e-4), ("memory", 1e-3)):
+        assert (out[k].cpu() - torch.from_numpy(fx["out_" + k])).abs().max().item() < tol, k
+    ref = torch.from_numpy(fx["out_pred_masks"])
+    d = (out["pred_masks"].cpu() - ref).abs().max().item()
+    assert d < 5e-3 and d <= 2e-5 * float(ref.abs().max()), d
+    assert O.mask_iou(out["pred_masks"].cpu() > 0, ref > 0) > 1 - 1e-3
+    for i in range(3):
+        assert (out["aux_outputs"][i]["pred_masks"].cpu() - torch.from_numpy(fx[f"aux{i}_pred_masks"])).abs().max().item() < 5e-3
+    for o in outs[1:]:
+        for k in ("pred_logits", "pred_boxes", "pred_masks", "memory"):
+            assert torch.equal(o[k], out[k]), k
+    # through the reference's own boundary: targets[0]['valid_indices'] (token ids; the text encoder differs from the fixture's,
+    # so only shapes and the frame count are asserted here)
+    ids = torch.randint(3, 50000, (1, 9))
+    o2 = model([frames], ids, [{"size": torch.tensor([H, W]), "valid_indices": torch.tensor(vi)}])
+    assert tuple(o2["pred_masks"].shape) == (1, 1, 5, 18, 25) and tuple(o2["pred_logits"].shape) == (1, 1, 5, 1)
+    with pytest.raises(IndexError):
+        model([frames], ids, [{"size": torch.tensor([H, W]), "valid_indices": torch.tensor(T)}])
+
+
 def _free_port():
     import socket
     sock = socket.socket()

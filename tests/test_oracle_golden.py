@@ -157,6 +157,29 @@ def test_e2e_padded_clip_matches_reference():
         assert col.abs().max() <= 1.0 + 1e-6 and col.abs().min() < 0.999  # sin / cos of a huge angle, not a constant
 
 
+def test_e2e_valid_indices_single_frame_path_matches_reference():
+    """tce_rvos.py:233-243 (A2D / JHMDB: one annotated frame per clip): the reference run with targets[0]['valid_indices'] = 1
+    on a 3-frame clip; every output has t = 1, `memory` is the selected frame's."""
+    fx = load_npz("e2e_swin_t_valid_idx.npz")
+    T, H, W = (int(v) for v in fx["thw"])
+    sd = synth_sd_from_manifest("statedict_swin_t.json", int(fx["weights_salt"]))
+    frames = synth_frames(T, H, W, int(fx["frames_seed"]))
+    with torch.no_grad():
+        out = O.forward(sd, O.OracleConfig(), frames, torch.from_numpy(fx["text_hidden"]), torch.from_numpy(fx["text_pooled"]),
+                        img_size=(H, W), valid_index=int(fx["valid_index"]))
+    assert tuple(out["pred_masks"].shape) == (1, 1, 5, 18, 25) == tuple(fx["out_pred_masks"].shape)
+    for k, atol in (("pred_logits", 1e-4), ("pred_boxes", 1e-5), ("reference_points", 1e-5), ("pred_masks", 2e-3), ("memory", 1e-4)):
+        ref = torch.from_numpy(fx["out_" + k])
+        assert tuple(out[k].shape) == tuple(ref.shape), k
+        assert (out[k] - ref).abs().max().item() < atol, k
+    for i in range(3):
+        assert torch.allclose(out["aux_outputs"][i]["pred_masks"], torch.from_numpy(fx[f"aux{i}_pred_masks"]), rtol=1e-3, atol=2e-3)
+    # and it is NOT what the full clip gives for that frame (the frame-token / IQT stages mix the clip's frames)
+    with torch.no_grad():
+        full = O.forward(sd, O.OracleConfig(), frames, torch.from_numpy(fx["text_hidden"]), torch.from_numpy(fx["text_pooled"]), img_size=(H, W))
+    assert (full["pred_masks"][:, 1:2] - out["pred_masks"]).abs().max().item() > 1e-2
+
+
 @pytest.mark.slow
 def test_e2e_video_swin_t_config3_fullsize_matches_reference():
     """BASELINE config 3 (Video-Swin-T, T=8, 384x640) -- ~25 s of CPU."""
