@@ -185,6 +185,16 @@ int tce_msda_fused_valid_f32(const float* value, const float* proj, const float*
                              const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M, int32_t Lq,
                              int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
 
+/* Few-query form of the whole attention core WITHOUT the value projection of the frame ("sample, then project"): src [N,S,256] is
+ * the module's UN-projected input_flatten, wv [256,256] / bv [256] its value_proj (ms_deform_attn.py:95); out [N*Lq, 256] is what
+ * tce_msda_fused_valid_f32 returns on value = value_proj(src) with padded rows zero-filled (:96-97) -- the gather is linear in the
+ * value rows, so a head's 32 outputs are its slice of wv applied to the bilinear sample of the RAW rows, plus bias * (sum of the
+ * weights of the corners that exist).  For calls with a few dozen queries per frame (frame tokens, decoder queries:
+ * tce_deformable_transformer.py:447-454, 688-694) it removes a [N*S, 256] x [256, 256] projection per call.  M must be 8. */
+int tce_msda_fewq_raw_f32(const float* src, const float* wv, const float* bv, const float* proj, const float* ref, float* out,
+                          const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M, int32_t Lq,
+                          int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
+
 /* Sine position map of an un-padded [T,h,w] grid, channels-last [T*h*w, 2F] (+ optional per-channel addend,
  * the level embedding).  Reference: position_encoding.py:64-84 (normalize, scale 2*pi, the -0.5 shift). */
 int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, tceStream stream);

@@ -43,7 +43,7 @@ extern "C" int tce_set_range_flag(int32_t* flag) {
 
 // 2: round 2 changed tce_embed_ln_f32 / the GroupNorm workspace size and dropped three round-1 entries
 // 3: per-device range flag, window_attn3d on the matrix cores, per-site arithmetic (round 3)
-extern "C" int tce_abi_version(void) { return 4; }
+extern "C" int tce_abi_version(void) { return 5; }
 extern "C" const char* tce_last_error(void) { return g_err; }
 
 extern "C" int tce_graph_begin(tceStream stream) {

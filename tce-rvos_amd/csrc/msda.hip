@@ -636,6 +636,127 @@ __global__ void __launch_bounds__(256) msda_fused_fewq_kernel(const float* __res
   }
 }
 
+// Few-query form WITHOUT a value projection of the frame ("sample, then project"; round 5).  For the frame tokens (8 per frame)
+// and the decoder queries (5 per frame) the module's value = value_proj(src) is a 24100 x 256 x 256 GEMM per call at config 2
+// -- eight such launches per clip, four of them on the critical path between encoder layers -- of which the call then reads
+// 0.3 % of the rows.  The bilinear gather is linear in the value rows and the softmax weights of a head sum to one, so
+//     out_h = sum_k a_k sum_corner cw * [corner valid] * (W_h src(corner) + b_h) = W_h s_h + b_h w_h,
+//     s_h = sum_k a_k sum_corner cw [valid] src(corner)  (256 raw channels),   w_h = sum_k a_k sum_corner cw [valid]
+// (a corner outside the level or on a padded position contributes neither W_h src nor b_h: the reference zero-fills the value
+// rows AFTER the projection, ops/modules/ms_deform_attn.py:95-97, and grid_sample pads with zeros).  One WORKGROUP per (frame,
+// query, head): wave c4 samples input channels 64 c4 .. 64 c4 + 63 of all 16 points' four corner rows (lane = point p, channel
+// group of 16: every load of the call is in flight at once, as in the projected few-query form), the four waves meet in LDS and
+// the workgroup applies the head's 32 x 256 slice of value_proj.weight (+ bias * w_h) in exact fp32.
+__global__ void __launch_bounds__(256) msda_fewq_raw_kernel(const float* __restrict__ src, const float* __restrict__ wv,
+                                                            const float* __restrict__ bv, const float* __restrict__ proj,
+                                                            const float* __restrict__ ref, float* __restrict__ out, LevelInfo lv,
+                                                            int N, int S, int Lq, int L, int P, int ref_dim, int ref_per_frame) {
+  constexpr int M = 8, C = 256;
+  __shared__ __attribute__((aligned(16))) float s_lds[C];
+  __shared__ float w_lds;
+  const int tid = threadIdx.x, lane = tid & 63, c4 = tid >> 6;
+  const long long item = blockIdx.x;  // (n*Lq + q)*M + m
+  const int pj = lane >> 2, cq = lane & 3;
+  const int LP = L * P;
+  long long r = item;
+  const int m = (int)(r % M); r /= M;
+  const int q = (int)(r % Lq);
+  const int n = (int)(r / Lq);
+  const bool have = pj < LP;
+  float px = 0.f, py = 0.f, logit = -3.0e38f;
+  int l = 0;
+  if (have) {
+    l = pj / P;
+    const float* row = proj + ((long long)n * Lq + q) * (M * LP * 3);
+    const float ox = row[(m * LP + pj) * 2 + 0];
+    const float oy = row[(m * LP + pj) * 2 + 1];
+    logit = row[M * LP * 2 + m * LP + pj];
+    const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+    if (ref_dim == 2) {
+      px = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+      py = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
+    } else {
+      px = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+      py = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
+    }
+  }
+  float mx = logit;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float e = have ? __expf(logit - mx) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float wgt = e / sum;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float weff = 0.f;
+  if (have) {
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const float h_im = py * (float)Hl - 0.5f, w_im = px * (float)Wl - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+      const float* vbase = src + ((long long)n * S + lv.start[l]) * C + c4 * 64 + cq * 16;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v[4][4];
+      const int Hv = lv.hv[l], Wv = lv.wv[l];
+      const bool ok[4] = {h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv, h_low >= 0 && w_high < Wv && h_low < Hv,
+                          h_high < Hv && w_low >= 0 && w_low < Wv, h_high < Hv && w_high < Wv};
+      const long long pos[4] = {(long long)h_low * Wl + w_low, (long long)h_low * Wl + w_high, (long long)h_high * Wl + w_low,
+                                (long long)h_high * Wl + w_high};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[c][g] = z;
+        if (ok[c]) {
+          const float* pv = vbase + pos[c] * C;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v[c][g] = *reinterpret_cast<const f32x4*>(pv + 4 * g);
+        }
+      }
+      const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc[i] = wgt * (cw[0] * v[0][i >> 2][i & 3] + cw[1] * v[1][i >> 2][i & 3] + cw[2] * v[2][i >> 2][i & 3] + cw[3] * v[3][i >> 2][i & 3]);
+      weff = wgt * ((ok[0] ? cw[0] : 0.f) + (ok[1] ? cw[1] : 0.f) + (ok[2] ? cw[2] : 0.f) + (ok[3] ? cw[3] : 0.f));
+    }
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    weff += __shfl_xor(weff, o, 64);
+  }
+  if (pj == 0) {
+    float* ps = s_lds + c4 * 64 + cq * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(ps + 4 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (tid == 0) w_lds = weff;  // identical in the four waves (same points, same corner tests)
+  }
+  __syncthreads();
+  // out[32 m + d] = W[32 m + d, :] . s + b[32 m + d] * w : thread (d = tid >> 3, part = tid & 7) takes 32 input channels
+  const int d = tid >> 3, part = tid & 7;
+  const float* wr = wv + (long long)(32 * m + d) * C + part * 32;
+  float dot = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * g);
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_lds + part * 32 + 4 * g);
+    dot = fmaf(w4[0], s4[0], dot);
+    dot = fmaf(w4[1], s4[1], dot);
+    dot = fmaf(w4[2], s4[2], dot);
+    dot = fmaf(w4[3], s4[3], dot);
+  }
+  dot += __shfl_xor(dot, 1, 64);
+  dot += __shfl_xor(dot, 2, 64);
+  dot += __shfl_xor(dot, 4, 64);
+  if (part == 0) out[item * 32 + d] = fmaf(bv[32 * m + d], w_lds, dot);
+}
+
 }  // namespace
 
 extern "C" int tce_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -776,5 +897,41 @@ extern "C" int tce_msda_fused_valid_f32(const float* value, const float* proj, c
   hipLaunchKernelGGL(msda_fused_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, proj, ref,
                      out, lv, N, S, M, Lq, L, P, ref_dim, ref_per_frame, total);
   TCE_CHECK_LAUNCH("tce_msda_fused_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_msda_fewq_raw_f32(const float* src, const float* wv, const float* bv, const float* proj, const float* ref,
+                                     float* out, const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M,
+                                     int32_t Lq, int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream) {
+  TCE_CHECK_ARG(src && wv && bv && proj && ref && out && shapes_hw, "tce_msda_fewq_raw_f32: null pointer");
+  TCE_CHECK_ARG(N > 0 && S > 0 && M == 8 && Lq > 0 && L > 0 && L <= MAXL && P > 0 && L * P <= 16,
+                "tce_msda_fewq_raw_f32: 8 heads of 32 channels (C = 256), L*P <= 16");
+  TCE_CHECK_ARG(ref_dim == 2 || ref_dim == 4, "tce_msda_fewq_raw_f32: ref_dim must be 2 or 4");
+  TCE_CHECK_ARG(tce_aligned16(src) && tce_aligned16(wv), "tce_msda_fewq_raw_f32: src / wv must be 16-byte aligned");
+  TCE_CHECK_ARG((long long)N * Lq * M <= 65536, "tce_msda_fewq_raw_f32: the few-query form is for <= 65536 (frame, query, head) items");
+  LevelInfo lv;
+  int start = 0;
+  for (int l = 0; l < MAXL; ++l) {
+    if (l < L) {
+      lv.H[l] = shapes_hw[2 * l];
+      lv.W[l] = shapes_hw[2 * l + 1];
+      lv.start[l] = start;
+      start += lv.H[l] * lv.W[l];
+      lv.hv[l] = valid_hw ? valid_hw[2 * l] : lv.H[l];
+      lv.wv[l] = valid_hw ? valid_hw[2 * l + 1] : lv.W[l];
+      TCE_CHECK_ARG(lv.hv[l] >= 1 && lv.hv[l] <= lv.H[l] && lv.wv[l] >= 1 && lv.wv[l] <= lv.W[l],
+                    "tce_msda_fewq_raw_f32: valid size of level %d outside 1..(H, W)", l);
+      lv.vry[l] = (float)lv.hv[l] / (float)lv.H[l];
+      lv.vrx[l] = (float)lv.wv[l] / (float)lv.W[l];
+    } else {
+      lv.H[l] = lv.W[l] = lv.hv[l] = lv.wv[l] = 1;
+      lv.start[l] = 0;
+      lv.vrx[l] = lv.vry[l] = 1.f;
+    }
+  }
+  TCE_CHECK_ARG(start == S, "tce_msda_fewq_raw_f32: sum(H*W)=%d != S=%d", start, S);
+  hipLaunchKernelGGL(msda_fewq_raw_kernel, dim3(N * Lq * M), dim3(256), 0, (hipStream_t)stream, src, wv, bv, proj, ref, out, lv, N, S,
+                     Lq, L, P, ref_dim, ref_per_frame);
+  TCE_CHECK_LAUNCH("tce_msda_fewq_raw_f32");
   return TCE_OK;
 }

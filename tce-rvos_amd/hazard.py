@@ -302,6 +302,11 @@ MODELS = {
          dense(_p(a[8]), a[9] * a[13] * a[11] * a[14] * a[15] * F)]),
     "tce_msda_fused_f32": lambda a: _msda(a[0], a[1], a[2], a[3], *a[5:13]),
     "tce_msda_fused_valid_f32": lambda a: _msda(a[0], a[1], a[2], a[3], *a[6:14]),
+    # (src, wv, bv, proj, ref, out, shapes, valid, N, S, M, Lq, L, P, ref_dim, ref_per_frame): reads the un-projected rows
+    "tce_msda_fewq_raw_f32": lambda a: (
+        [dense(_p(a[0]), a[8] * a[9] * 256 * F), dense(_p(a[1]), 256 * 256 * F), dense(_p(a[2]), 256 * F),
+         dense(_p(a[3]), a[8] * a[11] * a[10] * a[12] * a[13] * 3 * F), dense(_p(a[4]), (a[8] if a[15] else 1) * a[11] * a[14] * F)],
+        [dense(_p(a[5]), a[8] * a[11] * 256 * F)]),
     "tce_pos_sine2d_f32": lambda a: _pos(a, False),
     "tce_pos_sine2d_valid_f32": lambda a: _pos(a, True),
     "tce_resize_nearest_f32": _resize,

@@ -90,9 +90,45 @@ def _side_streams(device, slot, n=4):
     return st
 
 
+# Round 5: executables the model OWNS.  The captured hipGraph_t is never instantiated: its nodes are re-created, with their
+# parameters and edges, in a fresh graph (tce_graph_group with one input: csrc/capi.hip) and THAT is instantiated -- an executable
+# built from explicitly added nodes holds no reference to the capture's streams, so it can be destroyed when its cache entry is
+# evicted and the capture budget above no longer applies to it.  TCE_GRAPH_OWN_EXEC=0 restores the never-destroy path.
+GRAPH_OWN_EXEC = os.environ.get("TCE_GRAPH_OWN_EXEC", "1") != "0"
+_OWNED_LIVE = [0, 0]  # [alive now, destroyed so far]
+
+
+class _OwnedExec:
+    """A hipGraphExec_t built by tce_graph_group; destroyed with its cache entry (after a device sync by the owner)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        _OWNED_LIVE[0] += 1
+
+    def replay(self):
+        from ._lib import check, lib
+        check(lib().tce_graph_launch(self.handle, torch.cuda.current_stream().cuda_stream), "tce_graph_launch")
+
+    def destroy(self):
+        if self.handle is not None:
+            from ._lib import lib
+            lib().tce_graph_destroy(self.handle)
+            self.handle = None
+            _OWNED_LIVE[0] -= 1
+            _OWNED_LIVE[1] += 1
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def graph_state():
-    """Process-wide capture accounting: executables are never destroyed (see _ALL_GRAPHS), so captures are budgeted."""
-    return {"captured": len(_ALL_GRAPHS), "budget": GRAPH_BUDGET, "eager_forever": len(_ALL_GRAPHS) >= GRAPH_BUDGET}
+    """Process-wide capture accounting.  Owned executables (the default) are destroyed on eviction; executables of the legacy
+    path are never destroyed (see _ALL_GRAPHS) and are budgeted."""
+    return {"captured": len(_ALL_GRAPHS), "budget": GRAPH_BUDGET, "eager_forever": len(_ALL_GRAPHS) >= GRAPH_BUDGET,
+            "owned_alive": _OWNED_LIVE[0], "owned_destroyed": _OWNED_LIVE[1]}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -295,6 +331,9 @@ class ReferFormer(nn.Module):
         self._shape_cache = {}
         if getattr(self, "_graphs", None) or getattr(self, "_arenas", None):
             torch.cuda.synchronize()  # a replay / eager clip may still be running on these buffers
+        for ent in (getattr(self, "_graphs", None) or {}).values():
+            if isinstance(ent[0], _OwnedExec):
+                ent[0].destroy()
         self._graphs = OrderedDict()
         self._sightings = OrderedDict()
         self._text_cache = OrderedDict()
@@ -765,7 +804,7 @@ class ReferFormer(nn.Module):
             self._sightings.popitem(last=False)
         if n < self.graph_after:
             return False
-        if len(_ALL_GRAPHS) >= GRAPH_BUDGET:
+        if len(_ALL_GRAPHS) >= GRAPH_BUDGET and not (GRAPH_OWN_EXEC and os.environ.get("TCE_KEEP_GRAPHS", "0") != "1"):
             global _BUDGET_WARNED
             if not _BUDGET_WARNED:
                 _BUDGET_WARNED = True
@@ -908,7 +947,8 @@ class ReferFormer(nn.Module):
             return None
         torch.cuda.synchronize()
         keep = os.environ.get("TCE_KEEP_GRAPHS", "0") == "1"  # keep the hipGraph_t beside the executable (clip groups)
-        graph = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
+        own = GRAPH_OWN_EXEC and not keep
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if (keep or own) else torch.cuda.CUDAGraph()
         # capture_error_mode="thread_local": under the default ("global") mode ANY thread's event query is an error while this
         # thread captures -- and torch.distributed's RCCL watchdog thread polls the events of in-flight collectives (bench.py keeps
         # the previous step's all-gather in flight): it then dies with "operation not permitted when stream is capturing" and takes
@@ -916,9 +956,21 @@ class ReferFormer(nn.Module):
         # nothing capture-unsafe: arenas and side streams exist before the capture starts.
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = fn(res)
-        if keep:
+        if own:
+            import ctypes as C
+            from ._lib import lib
+            raw = (C.c_void_p * 1)(int(graph.raw_cuda_graph()))
+            ex = C.c_void_p()
+            if lib().tce_graph_group(raw, 1, C.byref(ex)) == 0 and ex.value:
+                del graph  # the captured hipGraph_t was never instantiated: nothing else refers to it
+                graph = _OwnedExec(ex)
+            else:  # a node kind the re-creation does not know (none in the shipped program): the legacy, never-destroyed path
+                own = False
+                graph.instantiate()
+        elif keep:
             graph.instantiate()
-        _ALL_GRAPHS.append(graph)  # executables outlive their cache entry (see _ALL_GRAPHS)
+        if not own:
+            _ALL_GRAPHS.append(graph)  # legacy executables outlive their cache entry (see _ALL_GRAPHS)
         try:
             plan = ops.CopyPlan(_flat_outputs(out)) if os.environ.get("TCE_COPYPLAN", "1") != "0" else None
         except ValueError:  # an output the segment copy cannot express: per-tensor clones
@@ -929,7 +981,9 @@ class ReferFormer(nn.Module):
         while len(self._graphs) > 1 and (len(self._graphs) > self.max_graphs or
                                          sum(e[4] for e in self._graphs.values()) > self.max_graph_bytes):
             torch.cuda.synchronize()  # the evicted graph may still be replaying
-            self._graphs.popitem(last=False)
+            _, old = self._graphs.popitem(last=False)
+            if isinstance(old[0], _OwnedExec):
+                old[0].destroy()  # owned executables go with their entry (legacy ones stay in _ALL_GRAPHS)
         return ent
 
     @staticmethod

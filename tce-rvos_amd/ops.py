@@ -573,6 +573,24 @@ def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_
     return out
 
 
+def msda_fewq_raw(src, wv, bv, proj, ref, shapes_hw, N, S, Lq, L, P, ref_dim, ref_per_frame, out=None, alloc=None, valid_hw=None):
+    """The attention core on the UN-projected rows src [N*S, 256] with the module's value_proj (wv [256,256], bv [256]) applied to
+    the bilinear sample (csrc/msda.hip, tce_msda_fewq_raw_f32): what msda_fused returns on value_proj(src), for calls with a few
+    queries per frame (no [N*S, 256] x [256, 256] projection)."""
+    _chk(src, "src")
+    if out is None:
+        out = alloc(N * Lq, 256) if alloc else torch.empty(N * Lq, 256, dtype=torch.float32, device=src.device)
+    arr = (C.c_int32 * (2 * L))(*[int(v) for hw in shapes_hw for v in hw])
+    varr = (C.c_int32 * (2 * L))(*[int(v) for hw in valid_hw for v in hw]) if valid_hw is not None else None
+    check(lib().tce_msda_fewq_raw_f32(src.data_ptr(), wv.data_ptr(), bv.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                      arr, varr, N, S, 8, Lq, L, P, ref_dim, 1 if ref_per_frame else 0, _stream()),
+          "tce_msda_fewq_raw_f32")
+    return out
+
+
+MSDA_RAW = os.environ.get("TCE_MSDA_RAW", "1") != "0"  # A/B: 0 = value_proj GEMM of the frame + the projected few-query form
+
+
 def pos_sine2d(T, h, w, F, device, add=None, out=None, alloc=None, valid=None):
     """valid = (hv, wv): rows / columns of the map that are not padding (padded clips)."""
     if out is None:

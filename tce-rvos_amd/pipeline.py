@@ -57,6 +57,7 @@ EARLY_PROJ = os.environ.get("TCE_EARLY_PROJ", "1") != "0"
 TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
 ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
 LAT1_AT = os.environ.get("TCE_LAT1_AT")
+SWIN3_FC2_SPLITK = int(os.environ.get("TCE_SWIN3_FC2_SPLITK", 1))
 if ABLATE or TAPS:
     import warnings
     warnings.warn(f"tce_rvos_amd: DIAGNOSTIC launch program (TCE_ABLATE={sorted(ABLATE)}, TCE_TAPS={int(TAPS)}): "
@@ -417,6 +418,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         A = ar.alloc
         m1 = ar.mark()
         proj = A(q_rows, 384)
+        vw = w[pre + "value_proj.weight"]
+        # a few queries per frame (frame tokens, decoder queries): "sample, then project" (csrc/msda.hip, msda_fewq_raw_kernel)
+        use_raw = ops.MSDA_RAW and q_per_frame <= 64 and T * q_per_frame * NH <= 65536 and vw.is_contiguous()
         if few(q_rows, "msda") and q_pos_shared and norm:
             # a few dozen queries: offsets|weights (+ the reference points' Linear + sigmoid) in one launch
             ref_t = ref
@@ -424,13 +428,20 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             if isinstance(ref, tuple):
                 ref_t = A(q_rows, 2)
                 segs.append((ref[0], ref[1], ref_t, 2, 2, False, ops.FR_SIGMOID))
-            fk_s = small_fork if small_fork is not None else _Fork(None)
-            with fk_s:
+            if use_raw:
+                # a few queries per frame: sample the un-projected rows and apply value_proj to the samples -- the [T*S, 256] x
+                # [256, 256] projection of the frame (24 us at config 2, on the path between two encoder layers) is not computed
                 FR(query, q_rows, D, segs, a2=q_pos, lda2=D, a2_rows=q_per_frame)
-            value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
-            fk_s.join()
-            samp = ops.msda_fused(value, proj, ref_t, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
-                                  out=A(q_rows, D), valid_hw=lvl_valid)
+                samp = ops.msda_fewq_raw(value_src, vw, w[pre + "value_proj.bias"], proj, ref_t, lvl_sizes, T, S, q_per_frame, 4, 4,
+                                         ref_dim, ref_per_frame, out=A(q_rows, D), valid_hw=lvl_valid)
+            else:
+                fk_s = small_fork if small_fork is not None else _Fork(None)
+                with fk_s:
+                    FR(query, q_rows, D, segs, a2=q_pos, lda2=D, a2_rows=q_per_frame)
+                value = _lin(A, value_src, T * S, D, vw, w[pre + "value_proj.bias"], D)
+                fk_s.join()
+                samp = ops.msda_fused(value, proj, ref_t, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
+                                      out=A(q_rows, D), valid_hw=lvl_valid)
             FR(samp, q_rows, D, [(w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, D, D, False, ops.FR_NONE)],
                res=resid, ldres=D)
             ln_(resid, norm)
@@ -450,19 +461,25 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             else:
                 gemm_ex(query, w[pre + "offaw.weight"], proj, q_rows, 384, D, D, D, 384, bias=w[pre + "offaw.bias"],
                         a2=q_pos, lda2=D)
-        if small_fork is not None:
-            with small_fork:
-                ref = ref() if callable(ref) else ref
-                offaw()
-        elif callable(ref):
-            ref = ref()
-        value = _lin(A, value_src, T * S, D, w[pre + "value_proj.weight"], w[pre + "value_proj.bias"], D)
-        if small_fork is not None:
-            small_fork.join()
-        else:
+        if use_raw:
+            ref = ref() if callable(ref) else ref
             offaw()
-        samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
-                              out=A(q_rows, D), valid_hw=lvl_valid)
+            samp = ops.msda_fewq_raw(value_src, vw, w[pre + "value_proj.bias"], proj, ref, lvl_sizes, T, S, q_per_frame, 4, 4,
+                                     ref_dim, ref_per_frame, out=A(q_rows, D), valid_hw=lvl_valid)
+        else:
+            if small_fork is not None:
+                with small_fork:
+                    ref = ref() if callable(ref) else ref
+                    offaw()
+            elif callable(ref):
+                ref = ref()
+            value = _lin(A, value_src, T * S, D, vw, w[pre + "value_proj.bias"], D)
+            if small_fork is not None:
+                small_fork.join()
+            else:
+                offaw()
+            samp = ops.msda_fused(value, proj, ref, lvl_sizes, T, S, NH, q_per_frame, 4, 4, ref_dim, ref_per_frame,
+                                  out=A(q_rows, D), valid_hw=lvl_valid)
         if norm:
             _proj_res_ln(samp, w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, q_rows,
                          w[norm + ".weight"], w[norm + ".bias"])
@@ -826,6 +843,8 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1, rep=1):
                     # last stage: ~1200 rows against K = 3072 -- 228 workgroups walking 96 K slices each; split-K: 61 -> 41 us
                     sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
                         if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1
+                    if SWIN3_FC2_SPLITK > 1 and C == 384 and 2048 < ntok <= 12000 and hid % (SWIN3_FC2_SPLITK * 32) == 0:
+                        sk = SWIN3_FC2_SPLITK  # A/B (TCE_SWIN3_FC2_SPLITK): 216 tiles of 128x64 walk 48 K slices each, one per CU
                     gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
                             ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
             ar.release(m0)

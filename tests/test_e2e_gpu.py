@@ -719,6 +719,7 @@ def test_graph_budget_exhaustion_stays_correct(models, monkeypatch):
     import warnings
     from tce_rvos_amd import model as M
     model = models("swin_t_p4w7", 17)
+    monkeypatch.setattr(M, "GRAPH_OWN_EXEC", False)   # the legacy path: executables the runtime must never see destroyed
     monkeypatch.setattr(M, "GRAPH_BUDGET", len(M._ALL_GRAPHS) + 2)
     monkeypatch.setattr(M, "_BUDGET_WARNED", False)
     H, W = 64, 96
@@ -738,6 +739,23 @@ def test_graph_budget_exhaustion_stays_correct(models, monkeypatch):
     assert st["eager_forever"] and st["captured"] == st["budget"]
     assert len(model._graphs) == 2   # two shapes were captured before the budget ran out, two run eagerly
     assert sum("capture budget" in str(w.message) for w in rec) == 1
+
+
+def test_graph_executables_are_destroyed_on_eviction():
+    """600 distinct clip shapes through a 3-entry graph cache in ONE process (a server sweeping shapes): every
+    shape's replay equals its eager pass bit for bit, evicted executables are destroyed (owned executables: nodes re-created in a
+    fresh graph), the capture budget is never touched and an evicted shape that comes back is captured again.  In a child
+    process: a runtime crash fails this test, not the session."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_cycle.py"), "--shapes", "600"], capture_output=True,
+                       text=True, timeout=1500)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    res = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    st = res["graph_state"]
+    assert res["own_exec"] and res["max_cached_entries"] <= 3
+    assert st["captured"] == 0 and not st["eager_forever"]          # nothing went to the never-destroyed list
+    assert st["owned_destroyed"] >= 600 - 3 and st["owned_alive"] <= 3
 
 
 def test_capture_falls_back_to_eager_when_a_branch_arena_is_too_small(models, monkeypatch):

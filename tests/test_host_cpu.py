@@ -30,7 +30,7 @@ def test_header_symbols_all_exported_and_bound(built_lib):
     l = ctypes.CDLL(built_lib)
     for name in declared | declared_dbg:
         assert hasattr(l, name), name
-    assert _lib.lib().tce_abi_version() == 4
+    assert _lib.lib().tce_abi_version() == 5
 
 
 def test_bad_arguments_are_rejected_with_a_message(built_lib):

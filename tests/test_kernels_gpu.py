@@ -516,6 +516,48 @@ def test_msda_fused(ops, N, Lq, ref_dim):
     close(out.view(N, Lq, M * 32), expect, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("N,Lq,ref_dim,padded", [(5, 8, 2, False), (3, 5, 4, False), (2, 8, 2, True), (40, 8, 2, False), (1, 1, 4, True)])
+def test_msda_fewq_raw_sample_then_project(ops, N, Lq, ref_dim, padded):
+    """tce_msda_fewq_raw_f32 ("sample, then project": the few-query attention core on the UN-projected rows, value_proj applied to
+    the bilinear samples) against the module's own order -- value = value_proj(src), padded rows zero-filled, then the gather
+    (ops/modules/ms_deform_attn.py:95-114) -- on the oracle, with out-of-range locations (missing corners drop their share of the
+    bias too) and padded levels."""
+    g = torch.Generator().manual_seed(N * 100 + Lq + ref_dim)
+    M, L, P = 8, 4, 4
+    shapes = [(9, 13), (5, 7), (3, 4), (2, 2)]
+    valid = [(7, 10), (4, 5), (2, 3), (1, 2)] if padded else None
+    S = sum(h * w for h, w in shapes)
+    src = torch.randn(N, S, 256, generator=g)
+    wv, bv = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g)
+    proj = torch.randn(N, Lq, M * L * P * 3, generator=g)
+    proj[..., :M * L * P * 2] *= 2.0
+    ref = torch.rand(N, Lq, ref_dim, generator=g) * 1.2 - 0.1
+    off = proj[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+    aw = torch.softmax(proj[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    vr = torch.tensor([[(wv_ / w), (hv_ / h)] for (h, w), (hv_, wv_) in zip(shapes, valid or shapes)], dtype=torch.float32)
+    if ref_dim == 2:
+        refl = ref[:, :, None, :] * vr[None, None]
+        norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+        loc = refl[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        refl = ref[:, :, None, :] * torch.cat([vr, vr], -1)[None, None]
+        loc = refl[:, :, None, :, None, :2] + off / P * refl[:, :, None, :, None, 2:] * 0.5
+    value = F.linear(src.double(), wv.double(), bv.double()).float().view(N, S, M, 32)
+    if padded:
+        pad = torch.cat([torch.ones(h, w, dtype=torch.bool).index_put_(
+            (torch.arange(hv_)[:, None], torch.arange(wv_)[None, :]), torch.tensor(False)).reshape(-1)
+            for (h, w), (hv_, wv_) in zip(shapes, valid)])
+        value = value.masked_fill(pad[None, :, None, None], 0.0)
+    expect = O.msda_core(value, shapes, loc, aw)
+    out = ops.msda_fewq_raw(dev(src.view(N * S, 256)), dev(wv), dev(bv), dev(proj), dev(ref), shapes, N, S, Lq, L, P, ref_dim, True,
+                            valid_hw=valid)
+    close(out.view(N, Lq, 256), expect, 1e-4, 1e-4)
+    # and against the projected few-query kernel on the HIP-projected value (the path it replaces)
+    vd = ops.gemm(dev(src.view(N * S, 256)), dev(wv), bias=dev(bv))
+    old = ops.msda_fused(vd, dev(proj), dev(ref), shapes, N, S, M, Lq, L, P, ref_dim, True, valid_hw=valid)
+    assert float((old - out).abs().max()) <= 2e-5 * float(expect.abs().max()) + 1e-6
+
+
 def test_pos_sine2d(ops):
     for T, h, w in [(2, 9, 13), (1, 45, 80)]:
         ref = O.pos_sine_2d(torch.zeros(T, h, w, dtype=torch.bool), 128).permute(0, 2, 3, 1).reshape(T * h * w, 256)
