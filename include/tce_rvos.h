@@ -195,6 +195,11 @@ int tce_msda_fewq_raw_f32(const float* src, const float* wv, const float* bv, co
                           const int32_t* shapes_hw, const int32_t* valid_hw, int32_t N, int32_t S, int32_t M, int32_t Lq,
                           int32_t L, int32_t P, int32_t ref_dim, int32_t ref_per_frame, tceStream stream);
 
+/* contrastive_cal (tce_rvos.py:318-319,512-521; --contrastive): out[t] = cosine similarity (eps 1e-6) between the mean over the S
+ * rows of frame t of memory [T,S,C] and the sentence feature sent[t / frames_per_clip] ([clips, C]); ws: T*32*C floats. */
+int tce_contrastive_f32(const float* memory, const float* sent, float* out, float* ws, int32_t T, int32_t S, int32_t C,
+                        int32_t frames_per_clip, tceStream stream);
+
 /* Sine position map of an un-padded [T,h,w] grid, channels-last [T*h*w, 2F] (+ optional per-channel addend,
  * the level embedding).  Reference: position_encoding.py:64-84 (normalize, scale 2*pi, the -0.5 shift). */
 int tce_pos_sine2d_f32(float* out, const float* add, int32_t T, int32_t h, int32_t w, int32_t F, tceStream stream);

@@ -61,6 +61,8 @@ class OracleConfig:
     vlblock: bool = True
     aux_loss: bool = True
     num_classes: int = 1
+    vis_loss: bool = False     # --vis_loss: visible_embed heads (tce_rvos.py:62-63,336-363)
+    contrastive: bool = False  # --contrastive: contrastive_cal (tce_rvos.py:318-319,512-521)
 
     @property
     def is_video_swin(self):
@@ -948,11 +950,13 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidde
     stages["hs"] = hs
 
     # heads (:330-365)
-    classes, coords = [], []
+    classes, coords, visibles = [], [], []
     for lvl in range(hs.shape[0]):
         reference = inverse_sigmoid(init_ref if lvl == 0 else inter_ref[lvl - 1])
         ci = lvl if cfg.with_box_refine else 0
         oc = linear(hs[lvl], sd[f"class_embed.{ci}.weight"], sd[f"class_embed.{ci}.bias"])
+        if cfg.vis_loss:
+            visibles.append(linear(hs[lvl], sd[f"visible_embed.{ci}.weight"], sd[f"visible_embed.{ci}.bias"]))
         tmp = _mlp(sd, f"bbox_embed.{ci}.", hs[lvl], 3)
         if reference.shape[-1] == 4:
             tmp = tmp + reference
@@ -963,6 +967,11 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidde
         coords.append(torch.sigmoid(tmp))
     out = {"pred_logits": classes[-1].view(b, t, cfg.num_queries, -1),
            "pred_boxes": coords[-1].view(b, t, cfg.num_queries, 4)}
+    if cfg.vis_loss:
+        out["pred_visible"] = visibles[-1].view(b, t, cfg.num_queries, 1)
+    if cfg.contrastive:  # contrastive_cal :512-521 ("enc_outputs_class" of the non-two-stage transformer IS the encoder memory)
+        vis_mem = memory.view(b, t, memory.shape[1], -1).mean(2)
+        out["contrastive"] = F.cosine_similarity(vis_mem, text_sent.view(b, 1, -1).repeat(1, t, 1), dim=2, eps=1e-6)
 
     # pixel decoder + dynamic conv (:367-380)
     mask_features = pixel_decoder(sd, cfg, feats, feat_masks, text_feat, text_mask, poses, mem_feats, t)
@@ -978,6 +987,9 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, frames: Tensor, text_hidde
         out["aux_outputs"] = [{"pred_logits": classes[i].view(b, t, cfg.num_queries, -1),
                                "pred_boxes": coords[i].view(b, t, cfg.num_queries, 4),
                                "pred_masks": seg[i]} for i in range(len(seg) - 1)]
+        if cfg.vis_loss:
+            for i in range(len(seg) - 1):
+                out["aux_outputs"][i]["pred_visible"] = visibles[i].view(b, t, cfg.num_queries, 1)
     out["reference_points"] = inter_ref[-2, :, :, :2].view(b, t, cfg.num_queries, 2)
     out["memory"] = memory
     if return_stages:

@@ -89,6 +89,7 @@ SIGNATURES = {
                                        i32, c_f]),
     "tce_msda_fewq_raw_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, i32, i32, i32,
                                     i32, c_f]),
+    "tce_contrastive_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_pos_sine2d_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_pos_sine2d_valid_f32": (i32, [c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),

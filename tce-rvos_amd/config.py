@@ -51,6 +51,8 @@ class ModelConfig:
     aux_loss: bool = True
     num_classes: int = 1
     text_hidden: int = 768
+    vis_loss: bool = False      # --vis_loss: visible_embed heads -> out['pred_visible'] (tce_rvos.py:62-63,328-363)
+    contrastive: bool = False   # --contrastive: out['contrastive'] = cos(mean_S memory, sentence feature) (:318-319,512-521)
 
     @property
     def is_resnet(self):
@@ -87,9 +89,6 @@ def config_from_args(args) -> ModelConfig:
     else:
         ds = getattr(args, "dataset_file", "ytvos")
         num_classes = {"ytvos": 65, "davis": 78, "a2d": 1, "jhmdb": 1}.get(ds, 91)  # tce_rvos.py:639-649
-    for flag in ("vis_loss", "contrastive"):
-        if getattr(args, flag, False):
-            raise NotImplementedError(f"--{flag} is a training-only branch outside the hot path")
     if getattr(args, "f_token", 0) < 0:
         raise NotImplementedError("f_token < 0 (LastLayerAsToken) is not on the hot path")
     if getattr(args, "controller_layers", 3) != 3 or getattr(args, "dynamic_mask_channels", 8) != 8:
@@ -106,7 +105,7 @@ def config_from_args(args) -> ModelConfig:
         f_token=getattr(args, "f_token", 0), qtrans=bool(getattr(args, "qtrans", False)),
         with_box_refine=bool(getattr(args, "with_box_refine", False)), mask_dim=getattr(args, "mask_dim", 256),
         rel_coord=True, vlblock=bool(getattr(args, "vlblock", True)), aux_loss=bool(getattr(args, "aux_loss", True)),
-        num_classes=num_classes)
+        num_classes=num_classes, vis_loss=bool(getattr(args, "vis_loss", False)), contrastive=bool(getattr(args, "contrastive", False)))
 
 
 def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
@@ -173,6 +172,9 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     n_pred = cfg.dec_layers if cfg.with_box_refine else 1
     for i in range(n_pred):
         lin(f"class_embed.{i}", cfg.num_classes, d)
+    if cfg.vis_loss:  # tce_rvos.py:62-63,119-120
+        for i in range(n_pred):
+            lin(f"visible_embed.{i}", 1, d)
     for i in range(n_pred):
         lin(f"bbox_embed.{i}.layers.0", d, d)
         lin(f"bbox_embed.{i}.layers.1", d, d)

@@ -1,19 +1,15 @@
 // Split-fp16 GEMM, small-tile instantiations (128x64 and 64x64, 4 waves) + the diagnostics entry points.
 #include "gemm_f16x3_kernel.h"
-#include <stdlib.h>
 
 int tce_gemm_f16x3_big_set_stamp(long long* dev_buf);
 int tce_gemm_f16x3_big_set_epilogue(int lds_staged);
 
 int tce_gemm_f16x3_launch_small(const tceGemmArgs& a, int tile, hipStream_t s) {
   if (tile == 12864) {
-    // Fewer workgroups than two per CU (Swin-T stage 3's fc2, 4600 x 384 x 1536: 216 tiles walking 48 K slices each, one wave per
-    // SIMD): nothing else on the CU hides a slice's memory round trip, so keep three slices in flight per thread -- as the 64x64
-    // tile does below.  TCE_GEMM_12864_DEPTH=1 (read once) restores the single-slice prefetch for A/B runs.
-    static const int deep = []() { const char* e = getenv("TCE_GEMM_12864_DEPTH"); return e ? atoi(e) : 3; }();
-    const long long blocks = (long long)tce_cdiv(a.M, 128) * tce_cdiv(a.N, 64) * (a.batch > 0 ? a.batch : 1);
-    if (deep >= 3 && blocks < 512 && a.K >= 256) launch<128, 64, 2, 3>(a, s);
-    else launch<128, 64, 2, 1>(a, s);
+    // (A three-slice register ring for this tile at low occupancy -- Swin-T stage 3's fc2, 216 workgroups walking 48 K slices --
+    // was built and measured in round 5: 4600 x 384 x 1536 36.7 us with one slice in flight, 40.2 us with three; the other shapes
+    // within 1 us, the clip 6.03 vs 6.07 ms.  Not kept: the tile is not bound by its loads' latency.)
+    launch<128, 64, 2, 1>(a, s);
   } else {
     // few workgroups = nothing else on the CU to hide a K step's memory round trip: keep 4 slices in flight
     const long long blocks = (long long)tce_cdiv(a.M, 64) * tce_cdiv(a.N, 64) * (a.batch > 0 ? a.batch : 1);

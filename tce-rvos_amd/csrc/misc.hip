@@ -405,3 +405,68 @@ extern "C" int tce_copy_segments(const tceCopySeg* segs, int32_t n, tceStream st
   TCE_CHECK_LAUNCH("tce_copy_segments");
   return TCE_OK;
 }
+
+// contrastive_cal (tce_rvos.py:512-521, --contrastive): per frame, cosine similarity (nn.CosineSimilarity(dim=2, eps=1e-6)) between
+// the mean of the frame's S memory rows and the clip's sentence feature.  Two launches: column sums of S / 32 row chunks per
+// frame (full 1 KiB rows, one column per thread), then one workgroup per frame finishes the mean and the three dot products.
+namespace {
+__global__ void __launch_bounds__(256) contrastive_partial_kernel(const float* __restrict__ mem, float* __restrict__ ws, const int S,
+                                                                  const int C, const int chunks) {
+  const int t = blockIdx.y, p = blockIdx.x, c = threadIdx.x;
+  if (c >= C) return;
+  const int r0 = (int)((long long)p * S / chunks), r1 = (int)((long long)(p + 1) * S / chunks);
+  const float* src = mem + ((long long)t * S + r0) * C + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += src[0];
+    a1 += src[C];
+    a2 += src[2 * (long long)C];
+    a3 += src[3 * (long long)C];
+    src += 4 * (long long)C;
+  }
+  for (; r < r1; ++r) {
+    a0 += src[0];
+    src += C;
+  }
+  ws[((long long)t * chunks + p) * C + c] = (a0 + a1) + (a2 + a3);
+}
+__global__ void __launch_bounds__(256) contrastive_final_kernel(const float* __restrict__ ws, const float* __restrict__ sent,
+                                                                float* __restrict__ out, const int S, const int C, const int chunks,
+                                                                const int frames_per_clip, const float eps) {
+  __shared__ float red[3][4];
+  const int t = blockIdx.x, c = threadIdx.x;
+  float m = 0.f, s = 0.f;
+  if (c < C) {
+    for (int p = 0; p < chunks; ++p) m += ws[((long long)t * chunks + p) * C + c];
+    m /= (float)S;
+    s = sent[(long long)(t / frames_per_clip) * C + c];
+  }
+  const float ms = wave_sum(m * s), mm = wave_sum(m * m), ss = wave_sum(s * s);
+  if ((c & 63) == 0) {
+    red[0][c >> 6] = ms;
+    red[1][c >> 6] = mm;
+    red[2][c >> 6] = ss;
+  }
+  __syncthreads();
+  if (c == 0) {
+    const float dot = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float n1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float n2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    // ATen cosine_similarity: x.y / sqrt(clamp(|x|^2 |y|^2, eps^2))
+    out[t] = dot / sqrtf(fmaxf(n1 * n2, eps * eps));
+  }
+}
+}  // namespace
+
+extern "C" int tce_contrastive_f32(const float* memory, const float* sent, float* out, float* ws, int32_t T, int32_t S, int32_t C,
+                                   int32_t frames_per_clip, tceStream stream) {
+  TCE_CHECK_ARG(memory && sent && out && ws && T > 0 && S > 0 && C > 0 && C <= 256 && frames_per_clip > 0 && T % frames_per_clip == 0,
+                "tce_contrastive_f32: bad arguments (C <= 256, T a multiple of the clip length)");
+  const int chunks = 32;
+  hipLaunchKernelGGL(contrastive_partial_kernel, dim3(chunks, T), dim3(256), 0, (hipStream_t)stream, memory, ws, S, C, chunks);
+  hipLaunchKernelGGL(contrastive_final_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, ws, sent, out, S, C, chunks, frames_per_clip,
+                     1e-6f);
+  TCE_CHECK_LAUNCH("tce_contrastive_f32");
+  return TCE_OK;
+}

@@ -307,6 +307,9 @@ MODELS = {
         [dense(_p(a[0]), a[8] * a[9] * 256 * F), dense(_p(a[1]), 256 * 256 * F), dense(_p(a[2]), 256 * F),
          dense(_p(a[3]), a[8] * a[11] * a[10] * a[12] * a[13] * 3 * F), dense(_p(a[4]), (a[8] if a[15] else 1) * a[11] * a[14] * F)],
         [dense(_p(a[5]), a[8] * a[11] * 256 * F)]),
+    # (memory, sent, out, ws, T, S, C, frames_per_clip)
+    "tce_contrastive_f32": lambda a: ([dense(_p(a[0]), a[4] * a[5] * a[6] * F), dense(_p(a[1]), (a[4] // a[7]) * a[6] * F)],
+                                      [dense(_p(a[2]), a[4] * F), dense(_p(a[3]), a[4] * 32 * a[6] * F)]),
     "tce_pos_sine2d_f32": lambda a: _pos(a, False),
     "tce_pos_sine2d_valid_f32": lambda a: _pos(a, True),
     "tce_resize_nearest_f32": _resize,

@@ -255,6 +255,8 @@ class ReferFormer(nn.Module):
         else:  # one head listed under every level's name (tce_rvos.py:127-130)
             for i in range(1, cfg.dec_layers):
                 self.class_embed.add_module(str(i), self.class_embed._modules["0"])
+                if cfg.vis_loss:
+                    self.visible_embed.add_module(str(i), self.visible_embed._modules["0"])
                 self.bbox_embed.add_module(str(i), self.bbox_embed._modules["0"])
         if text_encoder is None:
             text_encoder = build_text_encoder(args)

@@ -737,6 +737,13 @@ def box_refine(tmp, ref, out=None, alloc=None):
     return out
 
 
+def contrastive(memory, sent, T, S, Cn, frames_per_clip, out, ws):
+    """out[t] = cos(mean_S memory[t], sent[t // frames_per_clip]) (contrastive_cal, tce_rvos.py:512-521)."""
+    check(lib().tce_contrastive_f32(memory.data_ptr(), sent.data_ptr(), out.data_ptr(), ws.data_ptr(), T, S, Cn, frames_per_clip,
+                                    _stream()), "tce_contrastive_f32")
+    return out
+
+
 def mask_pack(params, nl, T, Q, Cm, w0f, tail):
     check(lib().tce_mask_pack_f32(params.data_ptr(), w0f.data_ptr(), tail.data_ptr(), nl, T, Q, Cm, _stream()),
           "tce_mask_pack_f32")

@@ -57,7 +57,7 @@ EARLY_PROJ = os.environ.get("TCE_EARLY_PROJ", "1") != "0"
 TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
 ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
 LAT1_AT = os.environ.get("TCE_LAT1_AT")
-SWIN3_FC2_SPLITK = int(os.environ.get("TCE_SWIN3_FC2_SPLITK", 1))
+SWIN3_FC2_SPLITK = int(os.environ.get("TCE_SWIN3_FC2_SPLITK", 2))
 if ABLATE or TAPS:
     import warnings
     warnings.warn(f"tce_rvos_amd: DIAGNOSTIC launch program (TCE_ABLATE={sorted(ABLATE)}, TCE_TAPS={int(TAPS)}): "
@@ -607,6 +607,7 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         hs = A(nl, T * Q, D)
         inter_ref = A(nl, T * Q, 4)
         logits = A(nl, T * Q, cfg.num_classes)
+        vis = A(nl, T * Q, 1) if cfg.vis_loss else None  # visible_embed heads (--vis_loss, tce_rvos.py:336-338)
         logits_done = [False] * nl
         qpos = w["query_embed.weight"]  # [Q, D], shared by all frames
         if few(Q, "dec"):  # Linear + sigmoid in one launch
@@ -661,9 +662,12 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 if few(T * Q, "dec"):
                     t3 = A(T * Q, 4)
                     # the level's class head reads the same rows: it rides in the box MLP's first launch
-                    FR(tgt, T * Q, D, [(w[bp + "0.weight"], w[bp + "0.bias"], t1, D, D, False, ops.FR_RELU),
-                                       (w[f"class_embed.{lid}.weight"], w[f"class_embed.{lid}.bias"], logits[lid], cfg.num_classes,
-                                        cfg.num_classes, False, ops.FR_NONE)])
+                    segs = [(w[bp + "0.weight"], w[bp + "0.bias"], t1, D, D, False, ops.FR_RELU),
+                            (w[f"class_embed.{lid}.weight"], w[f"class_embed.{lid}.bias"], logits[lid], cfg.num_classes,
+                             cfg.num_classes, False, ops.FR_NONE)]
+                    if vis is not None:
+                        segs.append((w[f"visible_embed.{lid}.weight"], w[f"visible_embed.{lid}.bias"], vis[lid], 1, 1, False, ops.FR_NONE))
+                    FR(tgt, T * Q, D, segs)
                     logits_done[lid] = True
                     FR(t1, T * Q, D, [(w[bp + "1.weight"], w[bp + "1.bias"], t2, D, D, False, ops.FR_RELU)])
                     FR(t2, T * Q, D, [(w[bp + "2.weight"], w[bp + "2.bias"], t3, 4, 4, False, ops.FR_NONE)])
@@ -684,8 +688,10 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             ci = lvl if cfg.with_box_refine else 0  # without refinement one head is shared by all levels (:127-130)
             gemm_ex(hs[lvl], w[f"class_embed.{ci}.weight"], logits[lvl], T * Q, cfg.num_classes, D, D, D, cfg.num_classes,
                     bias=w[f"class_embed.{ci}.bias"])
+            if vis is not None:
+                gemm_ex(hs[lvl], w[f"visible_embed.{ci}.weight"], vis[lvl], T * Q, 1, D, D, D, 1, bias=w[f"visible_embed.{ci}.bias"])
         if cfg.with_box_refine:
-            return hs, inter_ref, inter_ref, 4, logits
+            return hs, inter_ref, inter_ref, 4, logits, vis
         # no refinement: every layer saw the initial 2-d reference points; boxes come from the shared bbox_embed
         # applied to each level's hs (+ inverse_sigmoid(ref) on xy), tce_rvos.py:330-349
         refs2 = ops.tile(init_ref, nl, out=A(nl, T * Q, 2))
@@ -696,12 +702,12 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         gemm_ex(t1, w[bp + "1.weight"], t2, nl * T * Q, D, D, D, D, D, bias=w[bp + "1.bias"], act=ACT_RELU)
         t3 = _lin(A, t2, nl * T * Q, D, w[bp + "2.weight"], w[bp + "2.bias"], 4)
         ops.box_refine(t3, refs2, out=inter_ref)
-        return hs, inter_ref, refs2, 2, logits
+        return hs, inter_ref, refs2, 2, logits, vis
 
     npar = cfg.num_gen_params
     dec_fork = _Fork(side_stream if side_arena is not None else None)
     with dec_fork, model.arith("decoder"):
-        hs, boxes, mask_refs, ref_ld, logits = decoder_branch()
+        hs, boxes, mask_refs, ref_ld, logits, vis = decoder_branch()
         tap("dec.hs", hs)
         # controller MLP + parameter packing of the dynamic mask head (:371-373, 536-559): depend on hs only, so they
         # ride in the decoder branch instead of the main chain's tail
@@ -723,6 +729,10 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         w0f = dA(T, nl * Q * 8, cfg.mask_dim)
         tail = dA(nl, T * Q, 112)
         ops.mask_pack(params, nl, T, Q, cfg.mask_dim, w0f, tail)
+        contrast = None
+        if cfg.contrastive:  # contrastive_cal (tce_rvos.py:512-521): cos(mean over the S positions of a frame's memory, sentence feature)
+            contrast = dA(T)
+            ops.contrastive(memory, sent, T, S, D, Tc, contrast, dA(T * 32 * D))
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
@@ -748,10 +758,17 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         "pred_boxes": keep(boxes[-1].reshape(1, T, Q, 4)),
         "pred_masks": keep(masks[-1].reshape(1, T, Q, h4, w4)),
     }
+    if vis is not None:
+        out["pred_visible"] = keep(vis[-1].reshape(1, T, Q, 1))
+    if contrast is not None:
+        out["contrastive"] = keep(contrast.reshape(1, T))  # [b, t] (a clip group: the clips' frames back to back, like every output)
     if cfg.aux_loss:
         out["aux_outputs"] = [{"pred_logits": keep(logits[i].reshape(1, T, Q, K)),
                                "pred_boxes": keep(boxes[i].reshape(1, T, Q, 4)),
                                "pred_masks": keep(masks[i].reshape(1, T, Q, h4, w4))} for i in range(nl - 1)]
+        if vis is not None:  # _set_aux_loss with outputs_visible (tce_rvos.py:396-404)
+            for i in range(nl - 1):
+                out["aux_outputs"][i]["pred_visible"] = keep(vis[i].reshape(1, T, Q, 1))
     if not model.training:
         out["reference_points"] = keep(mask_refs[-2].reshape(1, T, Q, ref_ld)[..., :2])
     out["memory"] = keep(memory.reshape(T, S, D))
@@ -844,7 +861,9 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1, rep=1):
                     sk = next((c for c in (3, 4, 2) if hid % (c * 32) == 0), 1) \
                         if (ntok <= 2048 and hid >= 2048 and ops.SPLITK_ENABLED) else 1
                     if SWIN3_FC2_SPLITK > 1 and C == 384 and 2048 < ntok <= 12000 and hid % (SWIN3_FC2_SPLITK * 32) == 0:
-                        sk = SWIN3_FC2_SPLITK  # A/B (TCE_SWIN3_FC2_SPLITK): 216 tiles of 128x64 walk 48 K slices each, one per CU
+                        # 216 tiles of 128x64 walk 48 K slices each, one workgroup per CU: two K halves = two co-resident workgroups per
+                        # CU hiding each other's stalls + one reduce pass: 6.03 -> 6.00 ms per clip (A/B twice in one call, gpurun_out/r6d)
+                        sk = SWIN3_FC2_SPLITK
                     gemm_ex(hdn, w[p + "mlp.fc2.weight"], x, ntok, C, hid, hid, hid, C, bias=w[p + "mlp.fc2.bias"], res=x,
                             ldres=C, res_mode=RES_ADD, splitk=sk, ws=A(sk * ntok * C) if sk > 1 else None)
             ar.release(m0)

@@ -28,6 +28,8 @@ Fixtures
   harness_cases.npz    caller harness H (inference_ytvos.py:238-250): logits+masks -> thresholded mask
   e2e_swin_t_valid_idx.npz  the A2D / JHMDB single-frame path: T=3 frames of 72x100 with targets[0]['valid_indices'] = 1
                        (tce_rvos.py:233-243: everything after the backbone sees that one frame; t -> 1)
+  e2e_swin_t_vis_contrastive.npz  the optional output keys of --vis_loss / --contrastive (pred_visible, contrastive) +
+                       statedict_swin_t_vis.json (visible_embed.* in the checkpoint contract)
   perop_swin_t.npz, perop_vswin_t.npz, perop_noqtrans.npz  (round 5, SURVEY 8c list (ii)-(vii)) inputs and outputs of the
                        reference's OWN sub-modules, captured by forward hooks while the reference runs a small clip with the
                        synthetic weights (weights regenerate from the salt): shifted + padded SwinTransformerBlock and its
@@ -339,8 +341,33 @@ def gen_valid_idx():
     print("e2e_swin_t_valid_idx.npz pred_masks", tuple(out["pred_masks"].shape))
 
 
+def gen_vis_contrastive():
+    """--vis_loss --contrastive (tce_rvos.py:62-63,318-319,336-365,512-521): the optional output keys pred_visible / contrastive."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tce_rvos_amd.weights import load_synth_weights
+    T, H, W, seed = 3, 72, 100, 22
+    model = rh.build_reference_model(rh.reference_args("swin_t_p4w7", extra=("--vis_loss", "--contrastive")), seed=0, roberta_layers=1)
+    load_synth_weights(model, salt=seed)
+    gen_statedict_manifest(model, "statedict_swin_t_vis.json")
+    cap = {}
+    model.text_encoder.register_forward_hook(
+        lambda m, i, o: cap.update(hid=o.last_hidden_state.detach(), pool=o.pooler_output.detach()))
+    frames = _synth_inputs(T, H, W, seed + 1)
+    with torch.no_grad():
+        out = model([frames], ["synthetic"], [{"size": torch.tensor((H, W))}])
+    fx = {"text_hidden": _np(cap["hid"]), "text_pooled": _np(cap["pool"]), "thw": np.asarray([T, H, W]),
+          "frames_seed": np.asarray(seed + 1), "weights_salt": np.asarray(seed), "cfg_backbone": np.asarray("swin_t_p4w7")}
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "pred_visible", "contrastive", "reference_points"):
+        fx["out_" + k] = _np(out[k])
+    for i, a in enumerate(out["aux_outputs"]):
+        fx[f"aux{i}_pred_visible"] = _np(a["pred_visible"])
+    np.savez_compressed(os.path.join(HERE, "e2e_swin_t_vis_contrastive.npz"), **fx)
+    print("e2e_swin_t_vis_contrastive.npz", {k: tuple(out[k].shape) for k in ("pred_visible", "contrastive")}, sorted(out))
+
+
 def gen_round5():
     gen_valid_idx()
+    gen_vis_contrastive()
     b = "backbone.0.body."
     gen_perop("perop_swin_t.npz", "swin_t_p4w7", T=3, H=72, W=100, seed=18, wrap_mask_head=True, modules=[
         b + "layers.0.blocks.1", b + "layers.0.blocks.1.attn", b + "layers.1.blocks.0", b + "layers.1.downsample",

@@ -575,6 +575,36 @@ def test_valid_indices_single_frame_path_matches_reference(models):
         model([frames], ids, [{"size": torch.tensor([H, W]), "valid_indices": torch.tensor(T)}])
 
 
+def test_vis_loss_and_contrastive_outputs_match_reference():
+    """A27's optional keys on the HIP path: --vis_loss (visible_embed heads riding in the box MLP's few-row launch ->
+    pred_visible, aux levels too) and --contrastive (tce_contrastive_f32) against the reference run with both flags."""
+    from tce_rvos_amd import build_model, load_synth_weights
+    fx = load_npz("e2e_swin_t_vis_contrastive.npz")
+    T, H, W = (int(v) for v in fx["thw"])
+    a = _args("swin_t_p4w7")
+    a.vis_loss, a.contrastive = True, True
+    model, _, _ = build_model(a)
+    model = model.cuda().eval()
+    load_synth_weights(model, int(fx["weights_salt"]))
+    model.repack()
+    frames = synth_frames(T, H, W, int(fx["frames_seed"])).cuda()
+    hid, pooled = torch.from_numpy(fx["text_hidden"])[0].cuda(), torch.from_numpy(fx["text_pooled"])[0].cuda()
+    outs = [model.forward_features(frames, hid, pooled, float(H), float(W)) for _ in range(3)]   # eager, capture, replay
+    torch.cuda.synchronize()
+    out = outs[0]
+    assert set(out) == {"pred_logits", "pred_boxes", "pred_masks", "pred_visible", "contrastive", "aux_outputs", "reference_points", "memory"}
+    for k, tol in (("pred_logits", 2e-3), ("pred_boxes", 1e-4), ("pred_visible", 2e-3), ("contrastive", 1e-5), ("pred_masks", 5e-3)):
+        ref = torch.from_numpy(fx["out_" + k])
+        assert tuple(out[k].shape) == tuple(ref.shape), k
+        assert (out[k].cpu() - ref).abs().max().item() < tol, k
+    for i in range(3):
+        assert (out["aux_outputs"][i]["pred_visible"].cpu() - torch.from_numpy(fx[f"aux{i}_pred_visible"])).abs().max().item() < 2e-3
+    for o in outs[1:]:
+        for k in ("pred_visible", "contrastive", "pred_masks"):
+            assert torch.equal(o[k], out[k]), k
+    assert model.hazard_check(frames, torch.randint(3, 50000, (1, 9)).cuda(), (H, W)).clean
+
+
 def _free_port():
     import socket
     sock = socket.socket()

@@ -95,6 +95,18 @@ def test_model_state_dict_contract_and_build_model_boundary():
         model([torch.zeros(2, 3, 32, 32)], ["a"], [{"size": torch.tensor([32, 32])}])  # CPU input: no CPU path
 
 
+def test_vis_loss_state_dict_contract():
+    """--vis_loss adds visible_embed.{0..3} (tce_rvos.py:62-63,119-120): same keys and shapes as the reference built with it."""
+    import argparse
+    from tce_rvos_amd import build_model
+    model, _, _ = build_model(argparse.Namespace(backbone="swin_t_p4w7", with_box_refine=True, binary=True, f_token=8, qtrans=True,
+                                                 vis_loss=True, contrastive=True, text_encoder_layers=1))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "statedict_swin_t_vis.json")))
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    assert set(sd) == set(ref) and "visible_embed.3.weight" in sd
+    assert all(tuple(sd[k].shape) == tuple(ref[k][0]) for k in ref)
+
+
 def test_plain_flags_state_dict_contract():
     """Without --with_box_refine / --f_token / --qtrans the reference lists its shared heads under every level's
     name and has no frame-token parameters: same keys and shapes here."""

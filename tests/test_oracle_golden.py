@@ -180,6 +180,25 @@ def test_e2e_valid_indices_single_frame_path_matches_reference():
     assert (full["pred_masks"][:, 1:2] - out["pred_masks"]).abs().max().item() > 1e-2
 
 
+def test_e2e_vis_loss_and_contrastive_outputs_match_reference():
+    """The optional output keys of A27 (tce_rvos.py:360-365): pred_visible (--vis_loss: visible_embed heads, aux levels included)
+    and contrastive (--contrastive: cosine of the frame-mean memory and the sentence feature) against the reference run with
+    both flags."""
+    fx = load_npz("e2e_swin_t_vis_contrastive.npz")
+    T, H, W = (int(v) for v in fx["thw"])
+    sd = synth_sd_from_manifest("statedict_swin_t_vis.json", int(fx["weights_salt"]))
+    frames = synth_frames(T, H, W, int(fx["frames_seed"]))
+    with torch.no_grad():
+        out = O.forward(sd, O.OracleConfig(vis_loss=True, contrastive=True), frames, torch.from_numpy(fx["text_hidden"]),
+                        torch.from_numpy(fx["text_pooled"]), img_size=(H, W))
+    for k, atol in (("pred_logits", 1e-4), ("pred_boxes", 1e-5), ("pred_masks", 2e-3), ("pred_visible", 1e-4), ("contrastive", 1e-5)):
+        ref = torch.from_numpy(fx["out_" + k])
+        assert tuple(out[k].shape) == tuple(ref.shape), k
+        assert (out[k] - ref).abs().max().item() < atol, k
+    for i in range(3):
+        assert torch.allclose(out["aux_outputs"][i]["pred_visible"], torch.from_numpy(fx[f"aux{i}_pred_visible"]), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.slow
 def test_e2e_video_swin_t_config3_fullsize_matches_reference():
     """BASELINE config 3 (Video-Swin-T, T=8, 384x640) -- ~25 s of CPU."""
