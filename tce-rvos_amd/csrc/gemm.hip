@@ -23,8 +23,11 @@ namespace {
 
 constexpr int BK = 16;
 
+// __launch_bounds__(256, 3): without the bound the compiler spread the 128x128 tile over 124 VGPRs + 64 AGPRs (two waves per SIMD);
+// with it the same code fits 112 registers, no spills: FOUR waves per SIMD (33 KB of LDS per workgroup), which is what keeps the
+// 64-cycle fp32 MFMA pipe fed across the per-slice barrier (round 5; the counters had shown it busy 67 % of the time).
 template <int BM, int BN, bool CONV>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
+__global__ void __launch_bounds__(256, 3) gemm_f32_kernel(const tceGemmArgs p, const int tiles_m, const int tiles_n) {
   constexpr int LDAS = BM + 4;
   constexpr int LDBS = BN + 4;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -148,18 +151,29 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const tceGemmArgs p, cons
     if (kt + 1 < nk) load_tiles(kt + 1);
     const float* As = As0 + buf * BK * LDAS + wm * WM + l31;
     const float* Bs = Bs0 + buf * BK * LDBS + wn * WN + l31;
+    // operands of k-step kk+1 are fetched while the MFMAs of step kk issue (round 5: the counters showed the matrix pipe idle a
+    // third of the time at two waves per SIMD -- every step waited for its own LDS reads; profiles/r05_mfma_util.txt)
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = As[lhi * LDAS + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = Bs[lhi * LDBS + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + lhi;
-      float a[TM], b[TN];
+      if (kk + 1 < BK / 2) {
+        const int k = (kk + 1) * 2 + lhi;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[k * LDAS + i * 32];
+        for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = As[k * LDAS + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDBS + j * 32];
+        for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = Bs[k * LDBS + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kk & 1][j], a[kk & 1][i], acc[i][j], 0, 0, 0);  // D[n][m]
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
