@@ -432,6 +432,16 @@ int tce_graph_begin(tceStream stream);
 int tce_graph_end(tceStream stream, void** graph_exec_out);
 int tce_graph_launch(void* graph_exec, tceStream stream);
 int tce_graph_destroy(void* graph_exec);
+/* graphs = n hipGraph_t handles (captured, NOT instantiated; e.g. torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()): builds ONE
+ * executable in which they are n components with no edge between them -- every kernel / memset / empty node is re-created with
+ * its parameters and edges in a fresh graph, which is then instantiated (launch: tce_graph_launch; free: tce_graph_destroy; the
+ * inputs are left untouched and may be destroyed afterwards).  With n = 1 this is how the host builds the executable of a clip
+ * (round 5): an executable made of explicitly added nodes keeps no reference to the capture's streams, so -- unlike one
+ * instantiated from the captured graph itself (a HIP runtime defect) -- it can be destroyed while other
+ * executables live.  Returns an error (and leaves *graph_exec_out alone) for node kinds it cannot re-create (memcpy, host,
+ * child-graph nodes: none in the shipped launch program).  (Round 3 used it with n = 2 to run two clips as one graph:
+ * bit-identical, not faster -- DESIGN.md section 3.8; TCE_GROUP_CHILD=1 in the environment: child-graph nodes instead.) */
+int tce_graph_group(void* const* graphs, int32_t n, void** graph_exec_out);
 
 /* ---------------------------------------------------------------------------------------------------
  * Few-row linear layers (R of a few dozen rows; csrc/fewrow.hip): up to three projections of the SAME rows in one launch,

@@ -25,11 +25,9 @@ int tce_debug_mha_set_split(int32_t on);
 /* tuning aid: 1 (default) = tce_msda_fused_f32 runs calls of <= 8192 (frame, query, head) items with one wavefront per item
  * (all 16 sampling points in flight); 0 = always 8 lanes per item (A/B timing and parity) */
 int tce_debug_msda_set_fewq(int32_t on);
-/* experiment (tools/pair_graph_probe.py): graphs = n hipGraph_t handles of captured clips (each with its own buffers); builds
- * ONE executable in which they are n components with no edge between them (every node re-created with its parameters and
- * edges; TCE_GROUP_CHILD=1: as child-graph nodes instead), launched with tce_graph_launch.  Bit-identical to single replays
- * and not faster (x1.01 at config 2; child-graph nodes x0.75): see DESIGN.md section 3.8.  The inputs are cloned. */
-int tce_graph_group(void* const* graphs, int32_t n, void** graph_exec_out);
+/* tuning aid: 0 (default) = tce_conv3x3_f32 picks 128- or 256-pixel workgroups by the rounds of 256 workgroups each form needs;
+ * 4 / 8 = always the 4-wave (128-pixel) / 8-wave (256-pixel) form (A/B timing and parity) */
+int tce_debug_conv3x3_set_waves(int32_t waves);
 #ifdef __cplusplus
 }
 #endif

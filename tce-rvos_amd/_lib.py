@@ -132,6 +132,7 @@ SIGNATURES = {
     "tce_graph_end": (i32, [c_f, C.POINTER(C.c_void_p)]),
     "tce_graph_launch": (i32, [C.c_void_p, c_f]),
     "tce_graph_destroy": (i32, [C.c_void_p]),
+    "tce_graph_group": (i32, [C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p)]),
 }
 
 # include/tce_rvos_debug.h: tuning / diagnostic entry points (tools/ only)
@@ -144,7 +145,7 @@ DEBUG_SIGNATURES = {
     "tce_debug_window_attn_set_mfma": (i32, [i32]),
     "tce_debug_mha_set_split": (i32, [i32]),
     "tce_debug_msda_set_fewq": (i32, [i32]),
-    "tce_graph_group": (i32, [C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p)]),
+    "tce_debug_conv3x3_set_waves": (i32, [i32]),
 }
 
 _LIB = None

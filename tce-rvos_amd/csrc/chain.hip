@@ -1026,14 +1026,19 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int CIN, bool SINGLE>
-__global__ void __launch_bounds__(256, 1) conv3x3_kernel(const ConvArgs p) {
-  constexpr int WAVES = 4, NTL = 8;
+// WAVES = 8 (round 5, A/B): 256 pixels per workgroup, two waves per SIMD sharing ONE weight ring -- half the weight bytes per pixel
+// through L2 -> CU, which is what bounds the kernel; each wave then moves 2 of a stage's 16 pieces and keeps shorter register rings
+// (XS 4, NW 3) to stay inside 256 registers.
+template <int CIN, bool SINGLE, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) conv3x3_kernel(const ConvArgs p) {
+  constexpr int NTL = 8;
+  constexpr int PW = 16 / WAVES;          // weight pieces a wave moves per stage
   constexpr int STAGE = 2 * NTL * PIECE;  // one k-step of weights: 16 KiB
   constexpr int R = 4;                    // LDS ring stages
-  constexpr int XS = 6, LX = XS + 1;      // operand ring slots (registers); the operand of step q is requested at mid-step q-LX
-  constexpr int NW = CONV_PAD_STAGES - 2, LW = NW + 2;      // weight stages in flight (registers); those of step s are requested at mid-step s-LW
-  constexpr int INFLIGHT = 6 * (LW - 3);  // loads younger than the weights a mid-step waits for (2 operand + 4 weight per mid-step)
+  constexpr int XS = WAVES == 4 ? 6 : 4, LX = XS + 1;  // operand ring slots (registers); the operand of step q is requested at mid-step q-LX
+  constexpr int NW = WAVES == 4 ? CONV_PAD_STAGES - 2 : 3, LW = NW + 2;  // weight stages in flight (registers); those of step s are requested at mid-step s-LW
+  constexpr int INFLIGHT = (2 + PW) * (LW - 3);  // loads younger than the weights a mid-step waits for (2 operand + PW weight per mid-step)
+  static_assert(LW <= CONV_PAD_STAGES, "the packed stream's zero padding covers the weight lead");
   constexpr int BODY = 12;                // unrolled steps: 4 channel chunks x 3 horizontal taps (lcm of 3 and R)
   constexpr int ITERS = 3 * (CIN / 64);   // (vertical tap, group of 4 chunks)
   constexpr int KS = BODY * ITERS;
@@ -1063,23 +1068,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kernel(const ConvArgs p) {
     }
   };
 
-  // weights: this wave moves pieces 4*wave .. 4*wave+3 of every stage (4 KiB, one float4 per lane and piece) through
+  // weights: this wave moves pieces PW*wave .. PW*wave+PW-1 of every stage (one float4 per lane and piece) through
   // registers into the ring
-  const float* wp = reinterpret_cast<const float*>(p.wpk + (long long)(4 * wave) * PIECE + lane * 16);
-  unsigned char* const wdst = smem + (4 * wave) * PIECE + lane * 16;
-  f32x4 wr[NW][4];
-  auto wload = [&](f32x4 (&dst)[4]) {
+  const float* wp = reinterpret_cast<const float*>(p.wpk + (long long)(PW * wave) * PIECE + lane * 16);
+  unsigned char* const wdst = smem + (PW * wave) * PIECE + lane * 16;
+  f32x4 wr[NW][PW];
+  auto wload = [&](f32x4 (&dst)[PW]) {
     if (!(CONV_ABL & 8)) {
       gload16<0>(dst[0], wp);
       gload16<PIECE>(dst[1], wp);
-      gload16<2 * PIECE>(dst[2], wp);
-      gload16<3 * PIECE>(dst[3], wp);
+      if constexpr (PW == 4) {
+        gload16<2 * PIECE>(dst[2], wp);
+        gload16<3 * PIECE>(dst[3], wp);
+      }
     }
     wp += STAGE / 4;
   };
-  auto wstore = [&](const f32x4 (&src)[4], const int stage) {
+  auto wstore = [&](const f32x4 (&src)[PW], const int stage) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wdst + stage * STAGE + q * PIECE) = src[q];
+    for (int q = 0; q < PW; ++q) *reinterpret_cast<f32x4*>(wdst + stage * STAGE + q * PIECE) = src[q];
   };
 
   f32x4 xr[XS][2];
@@ -1097,12 +1104,16 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kernel(const ConvArgs p) {
     gload16<64 * (J / 3) + 16>(dst[1], src);
   };
   // "every load up to n operations ago has landed"; the register tuples named here are what the following code reads
-  auto wait_loads = [&](auto nc, f32x4 (&xs)[2], f32x4 (&ws)[4]) {
+  auto wait_loads = [&](auto nc, f32x4 (&xs)[2], f32x4 (&ws)[PW]) {
     constexpr int N = (CONV_ABL & 24) ? 0 : decltype(nc)::value;
-    asm volatile("s_waitcnt vmcnt(%6)"
-                 : "+v"(xs[0]), "+v"(xs[1]), "+v"(ws[0]), "+v"(ws[1]), "+v"(ws[2]), "+v"(ws[3])
-                 : "n"(N)
-                 : "memory");
+    if constexpr (PW == 4) {
+      asm volatile("s_waitcnt vmcnt(%6)"
+                   : "+v"(xs[0]), "+v"(xs[1]), "+v"(ws[0]), "+v"(ws[1]), "+v"(ws[2]), "+v"(ws[3])
+                   : "n"(N)
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xs[0]), "+v"(xs[1]), "+v"(ws[0]), "+v"(ws[1]) : "n"(N) : "memory");
+    }
   };
   using nfl = std::integral_constant<int, INFLIGHT>;
 
@@ -1545,6 +1556,13 @@ extern "C" int tce_conv3x3_pack_f32(const float* w, void* packed, int32_t Cin, i
   return TCE_OK;
 }
 
+static int g_conv3_waves = 0;
+extern "C" int tce_debug_conv3x3_set_waves(int32_t waves) {
+  TCE_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, "tce_debug_conv3x3_set_waves: 0 (automatic), 4 or 8");
+  g_conv3_waves = waves;
+  return TCE_OK;
+}
+
 extern "C" int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, const float* bias, float* out, int64_t ldo,
                                int32_t T, int32_t H, int32_t W, int32_t Cin, int32_t N, tceStream stream) {
   TCE_CHECK_ARG(conv3x3_shape_ok(Cin, N), "tce_conv3x3_f32: unsupported shape Cin=%d N=%d (256 -> 256)", Cin, N);
@@ -1557,7 +1575,15 @@ extern "C" int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, 
   a.x = x; a.wpk = (const unsigned char*)packed; a.bias = bias; a.out = out;
   a.ldx = ldx; a.ldo = ldo; a.H = H; a.W = W; a.M = T * H * W;
   a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
-  if (a.single) hipLaunchKernelGGL((conv3x3_kernel<256, true>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  // 256-pixel (8-wave) workgroups halve the weight bytes per pixel; a round of them takes 1.75 x a round of 128-pixel workgroups
+  // (measured, tools/conv3_bench.py: 128400 px 508 -> 444 us, 72000 px 333 -> 337, 18000 px 100 -> 142): taken when the rounds of
+  // 256 workgroups that way cost less -- config 5 and clip groups, not the single config-2 clip.  TCE_CONV3_WAVES=4|8 / tce_debug_conv3x3_set_waves force one.
+  static const int env_force = []() { const char* e = getenv("TCE_CONV3_WAVES"); return e ? atoi(e) : 0; }();
+  const int force = g_conv3_waves ? g_conv3_waves : env_force;
+  const int r4 = tce_cdiv(tce_cdiv(a.M, 128), 256), r8 = tce_cdiv(tce_cdiv(a.M, 256), 256);
+  const int wide = force ? force : (4 * r4 > 7 * r8 ? 8 : 4);
+  if (wide == 8 && !a.single) hipLaunchKernelGGL((conv3x3_kernel<256, false, 8>), dim3(tce_cdiv(a.M, 256)), dim3(512), 0, (hipStream_t)stream, a);
+  else if (a.single) hipLaunchKernelGGL((conv3x3_kernel<256, true>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((conv3x3_kernel<256, false>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);
   TCE_CHECK_LAUNCH("tce_conv3x3_f32");
   return TCE_OK;

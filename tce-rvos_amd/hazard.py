@@ -382,7 +382,7 @@ MODELS = {
 NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode", "tce_set_gemm_mode_thread",
                 "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes",
                 "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_swin_attn_packed_bytes", "tce_thin_linear_splits", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
-                "tce_graph_destroy"} | set(_lib.DEBUG_SIGNATURES)
+                "tce_graph_destroy", "tce_graph_group"} | set(_lib.DEBUG_SIGNATURES)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

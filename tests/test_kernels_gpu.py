@@ -1137,8 +1137,17 @@ def test_copy_segments_plan_and_many(ops):
         ops.CopyPlan([base[:100:3]])  # neither dense nor a row gather
 
 
+@pytest.fixture(params=[4, 8])
+def conv_waves(request):
+    """Both forms of the pixel-stationary convolution: 128-pixel (4-wave) and 256-pixel (8-wave, round 5) workgroups."""
+    from tce_rvos_amd._lib import lib
+    lib().tce_debug_conv3x3_set_waves(request.param)
+    yield request.param
+    lib().tce_debug_conv3x3_set_waves(0)
+
+
 @pytest.mark.parametrize("T,H,W", [(1, 9, 13), (2, 32, 40), (1, 45, 80), (3, 17, 5)])
-def test_conv3x3_pixel_stationary(ops, T, H, W):
+def test_conv3x3_pixel_stationary(ops, conv_waves, T, H, W):
     """tce_conv3x3_f32 (pixel-stationary kernel) against torch conv2d in fp64 and against the implicit-GEMM path;
     image borders, a ragged last pixel block and pixels whose 3x3 neighbourhood crosses frames."""
     g = torch.Generator(device="cpu").manual_seed(11 + H)
@@ -1174,7 +1183,7 @@ def _evict_caches():
     del junk
 
 
-def test_conv3x3_cold_operands(ops):
+def test_conv3x3_cold_operands(ops, conv_waves):
     T, H, W = 5, 90, 160   # config 2's stride-4 map: 72000 pixels x 1 KiB = 73.7 MB in, 73.7 MB out
     g = torch.Generator(device="cpu").manual_seed(5)
     x_cl = torch.randn(T * H * W, 256, generator=g).cuda()
