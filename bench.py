@@ -39,9 +39,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "clips/s (T=5, 360×640, Swin-T) at 1/2/4/8 MI355X; mask IoU vs ref"
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_traffic.json")
-PMC_FALLBACK = os.path.join("profiles", "r03_pmc_traffic.json")
-LATENCY_SUMMARY = os.path.join("profiles", "r04_latency_bound.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r04_pmc_traffic.json")
+LATENCY_SUMMARY = os.path.join("profiles", "r05_latency_bound.json")
 
 
 def _pmc_traffic(kernel_prefix):

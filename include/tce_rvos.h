@@ -468,6 +468,15 @@ typedef struct {
   int64_t ldx, lda2, ldres;
   int32_t a2_rows, R, K, nseg;
   tceFewRowSeg seg[3];
+  /* round 5 (ABI 5), optional LayerNorm PROLOGUE (K <= 256): x rows are normalised over K (gamma g_in, beta be_in, eps_in) before
+   * the addend and the projections -- the post-norm LayerNorm in front of a few-row projection (tce_deformable_transformer.py:
+   * 454-455,468-469) rides in the projection's launch.  xn_out (optional, [R, K], pitch ldxn, must not overlap x / a2 / any out):
+   * the normalised rows are also written there (by the workgroups of output slab 0), for the residual stream. */
+  const float* g_in;
+  const float* be_in;
+  float* xn_out;
+  int64_t ldxn;
+  float eps_in;
 } tceFewRowArgs;
 int tce_fewrow_linear_f32(const tceFewRowArgs* args, tceStream stream);
 

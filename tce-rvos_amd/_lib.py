@@ -48,7 +48,8 @@ class FewRowSeg(C.Structure):
 class FewRowArgs(C.Structure):
     _fields_ = [("x", c_f), ("a2", c_f), ("res", c_f),
                 ("ldx", i64), ("lda2", i64), ("ldres", i64),
-                ("a2_rows", i32), ("R", i32), ("K", i32), ("nseg", i32), ("seg", FewRowSeg * 3)]
+                ("a2_rows", i32), ("R", i32), ("K", i32), ("nseg", i32), ("seg", FewRowSeg * 3),
+                ("g_in", c_f), ("be_in", c_f), ("xn_out", c_f), ("ldxn", i64), ("eps_in", f32)]
 
 
 class CopySeg(C.Structure):

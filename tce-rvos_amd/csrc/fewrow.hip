@@ -40,6 +40,10 @@ struct FrArgs {
   long long ldx, lda2, ldres;
   int a2_rows, R, K, nseg;
   FrSegDev seg[3];
+  const float *g_in, *be_in;  // optional LayerNorm prologue over K (K <= FR_KC: the whole row is staged at once)
+  float* xn_out;              // optional copy of the normalised rows (written by the workgroups of slab 0)
+  long long ldxn;
+  float eps_in;
 };
 
 // Thread (column c = tid & 7, row group g = tid >> 3) owns row g of the workgroup's 32-row pass (RPT = 1).  Rows past the
@@ -75,6 +79,16 @@ __global__ void __launch_bounds__(256) fewrow_linear_kernel(const FrArgs p) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < nr) {
           v = *reinterpret_cast<const f32x4*>(p.x + (long long)(r0 + r) * p.ldx + k0 + 4 * q);
+          if (p.g_in) {
+            // LayerNorm prologue: a wavefront holds the whole row (K = 4 * q4 <= 256: one float4 per lane), two-pass statistics
+            // like layernorm_kernel; `r` and `nr` are wave-uniform, so the shuffles run with all lanes of the wave
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)p.K;
+            const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+            const float rstd = rsqrtf(wave_sum(fmaf(d[0], d[0], fmaf(d[1], d[1], fmaf(d[2], d[2], d[3] * d[3])))) / (float)p.K + p.eps_in);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.g_in + 4 * q), b = *reinterpret_cast<const f32x4*>(p.be_in + 4 * q);
+            v = f32x4{d[0] * rstd * g[0] + b[0], d[1] * rstd * g[1] + b[1], d[2] * rstd * g[2] + b[2], d[3] * rstd * g[3] + b[3]};
+            if (p.xn_out && blockIdx.x == 0) *reinterpret_cast<f32x4*>(p.xn_out + (long long)(r0 + r) * p.ldxn + 4 * q) = v;
+          }
           if (sg.use_a2) {
             const int ra = p.a2_rows > 0 ? (r0 + r) % p.a2_rows : r0 + r;
             v += *reinterpret_cast<const f32x4*>(p.a2 + (long long)ra * p.lda2 + k0 + 4 * q);
@@ -149,6 +163,13 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
   };
   auto disjoint = [](const float* b0, const float* e0, const float* b1, const float* e1) { return e0 <= b1 || e1 <= b0; };
   FrArgs p;
+  p.g_in = a->g_in; p.be_in = a->be_in; p.xn_out = a->g_in ? a->xn_out : nullptr; p.ldxn = a->ldxn; p.eps_in = a->eps_in;
+  if (a->g_in) {
+    // the prologue needs the whole row in one staged chunk with every lane of a wave on it (lanes >= K/4 would sit out the shuffles)
+    TCE_CHECK_ARG(a->be_in && a->K == FR_KC && tce_aligned16(a->g_in) && tce_aligned16(a->be_in),
+                  "tce_fewrow_linear_f32: the LayerNorm prologue needs K = %d and 16-byte aligned gamma / beta", FR_KC);
+    TCE_CHECK_ARG(!a->xn_out || (a->ldxn >= a->K && a->ldxn % 4 == 0 && tce_aligned16(a->xn_out)), "tce_fewrow_linear_f32: xn_out pitch / alignment");
+  }
   p.x = a->x; p.a2 = a->a2; p.res = a->res;
   p.ldx = a->ldx; p.lda2 = a->lda2; p.ldres = a->ldres;
   p.a2_rows = a->a2_rows; p.R = a->R; p.K = a->K; p.nseg = a->nseg;
@@ -177,6 +198,16 @@ extern "C" int tce_fewrow_linear_f32(const tceFewRowArgs* a, tceStream stream) {
         const float *pb, *pe;
         span(a->seg[t].out, a->seg[t].ldo, a->seg[t].N, a->R, pb, pe);
         TCE_CHECK_ARG(disjoint(pb, pe, ob, oe), "tce_fewrow_linear_f32: outputs of segments %d and %d overlap", t, s);
+      }
+      if (a->g_in && a->xn_out) {  // the normalised copy is written while other workgroups read x / a2 and write their slabs
+        const float *nb, *ne;
+        span(a->xn_out, a->ldxn, a->K, a->R, nb, ne);
+        TCE_CHECK_ARG(disjoint(nb, ne, xb, xe) && disjoint(nb, ne, ob, oe), "tce_fewrow_linear_f32: xn_out overlaps x or segment %d's out", s);
+        if (a->a2) {
+          const float *ab, *ae;
+          span(a->a2, a->lda2, a->K, a->a2_rows > 0 ? a->a2_rows : a->R, ab, ae);
+          TCE_CHECK_ARG(disjoint(nb, ne, ab, ae), "tce_fewrow_linear_f32: xn_out overlaps a2");
+        }
       }
       if (a->res) {
         const float *rb, *re;

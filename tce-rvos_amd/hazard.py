@@ -174,6 +174,10 @@ def _fewrow(q):
         rd.append(strided(_p(q.a2), q.K * F, (q.a2_rows if q.a2_rows > 0 else q.R, q.lda2 * F)))
     if q.res:
         rd.append(strided(_p(q.res), q.seg[0].N * F, (q.R, q.ldres * F)))
+    if q.g_in:  # LayerNorm prologue (round 5)
+        rd += [dense(_p(q.g_in), q.K * F), dense(_p(q.be_in), q.K * F)]
+        if q.xn_out:
+            wr.append(strided(_p(q.xn_out), q.K * F, (q.R, q.ldxn * F)))
     return rd, wr
 
 

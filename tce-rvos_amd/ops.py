@@ -1176,10 +1176,16 @@ FEWROW_MAX_ROWS = int(os.environ.get("TCE_FEWROW_MAX_ROWS", 128))
 FR_NONE, FR_RELU, FR_SIGMOID, FR_GELU = 0, 1, 2, 3
 
 
-def fewrow_linear(x, R, K, segs, ldx=None, a2=None, lda2=0, a2_rows=0, res=None, ldres=0):
-    """segs: list of (W [N,K] (row-strided view ok), bias or None, out tensor, N, ldo, use_a2, act); res: added to segment 0."""
+def fewrow_linear(x, R, K, segs, ldx=None, a2=None, lda2=0, a2_rows=0, res=None, ldres=0, ln_in=None, eps_in=1e-5, xn_out=None):
+    """segs: list of (W [N,K] (row-strided view ok), bias or None, out tensor, N, ldo, use_a2, act); res: added to segment 0.
+    ln_in = (gamma, beta): LayerNorm of the x rows BEFORE the addend and the projections (K = 256); xn_out: the normalised rows
+    are also written there (a tensor that overlaps none of the operands)."""
     from ._lib import FewRowArgs
     q = FewRowArgs()
+    if ln_in is not None:
+        q.g_in, q.be_in, q.eps_in = ln_in[0].data_ptr(), ln_in[1].data_ptr(), eps_in
+        if xn_out is not None:
+            q.xn_out, q.ldxn = xn_out.data_ptr(), (xn_out.stride(0) if xn_out.dim() == 2 else K)
     q.x, q.ldx, q.R, q.K, q.nseg = x.data_ptr(), (K if ldx is None else ldx), R, K, len(segs)
     if a2 is not None:
         q.a2, q.lda2, q.a2_rows = a2.data_ptr(), lda2, a2_rows

@@ -58,6 +58,10 @@ TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
 ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
 LAT1_AT = os.environ.get("TCE_LAT1_AT")
 SWIN3_FC2_SPLITK = int(os.environ.get("TCE_SWIN3_FC2_SPLITK", 2))
+# norm1 / norm2 of the frame-token path in the prologue of the few-row launch that follows them (8 launches fewer per clip): measured
+# NOT faster -- 6.055 / 6.047 ms with it against 6.030 / 6.043 without (A/B twice in one call, gpurun_out/r6k): every workgroup of the
+# projection recomputes the rows' statistics (two wave reductions per row), which costs what the LayerNorm launch did.  Off.
+FTF_LN_FUSE = os.environ.get("TCE_FTF_LN_FUSE", "0") != "0"
 if ABLATE or TAPS:
     import warnings
     warnings.warn(f"tce_rvos_amd: DIAGNOSTIC launch program (TCE_ABLATE={sorted(ABLATE)}, TCE_TAPS={int(TAPS)}): "
@@ -400,17 +404,22 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
     if Fk > 0:
         token = ops.tile(w["transformer.encoder.memory_bus"], T, out=A(T * Fk, D))
         tpos = w["transformer.encoder.memory_pos"]
+        # norm1 / norm2 of the frame-token layer ride in the prologue of the few-row launch that follows them (qk|v of the token
+        # self-attention; k|v of the pixel <- token attention): the normalised rows ping-pong between two buffers (a prologue
+        # cannot normalise in place: other workgroups still read the rows).  2 launches fewer per layer on the path between layers.
+        ftf_fuse_ln = FTF_LN_FUSE and D == 256 and all(few(T * Fk, site) for site in ("msda", "ftf2", "ftf3"))
+        token_alt = A(T * Fk, D) if ftf_fuse_ln else None
     # free between the text join and the decoder fork
     tok_stream = side_stream if TOKFORK else None
 
     def msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
-             ar=ar, norm=None, small_fork=None, group="encoder.msda"):
+             ar=ar, norm=None, small_fork=None, group="encoder.msda", defer_norm=False):
         with model.arith(group):
             _msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid, ar, norm,
-                  small_fork)
+                  small_fork, defer_norm)
 
     def _msda(pre, query, q_rows, q_per_frame, q_pos, q_pos_shared, value_src, ref, ref_dim, ref_per_frame, resid,
-              ar, norm, small_fork):
+              ar, norm, small_fork, defer_norm=False):
         """resid <- LN_norm?(resid + output_proj(MSDA(query + q_pos, ref, value_proj(value_src)))).  query [T*q_per_frame, D].
         ref: the reference points, or (W, b) of the Linear whose sigmoid gives them (evaluated beside value_proj when
         small_fork is a _Fork: the few-row projections of the frame-token path run as a parallel branch next to the large
@@ -444,7 +453,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                                       out=A(q_rows, D), valid_hw=lvl_valid)
             FR(samp, q_rows, D, [(w[pre + "output_proj.weight"], w[pre + "output_proj.bias"], resid, D, D, False, ops.FR_NONE)],
                res=resid, ldres=D)
-            ln_(resid, norm)
+            if not defer_norm:  # (deferred: the LayerNorm rides in the prologue of the next few-row launch on these rows)
+                ln_(resid, norm)
             ar.release(m1)
             return
         if isinstance(ref, tuple):
@@ -515,8 +525,9 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
             token_ref = (w[fp + "reference_points.weight"], w[fp + "reference_points.bias"])
             if "ftf_tok" not in ABLATE:
                 msda(fp + "token_frame_atten.", token, T * Fk, Fk, tpos, True, src, token_ref, 2, True, token,
-                     norm=fp + "norm1", small_fork=_Fork(tok_stream))
-            tap(f"L{i}.token1", token)
+                     norm=fp + "norm1", small_fork=_Fork(tok_stream), defer_norm=ftf_fuse_ln)
+            if not ftf_fuse_ln:
+                tap(f"L{i}.token1", token)
             # (2) all T*F tokens attend to each other (:463-469)
             with model.arith("encoder.ftf"):
                 R = T * Fk
@@ -525,8 +536,15 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     qk = A(R, 2 * D)
                     if few(R, "ftf2"):  # q|k (token + position) and v in one launch
                         v = A(R, D)
-                        FR(token, R, D, [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
-                                         (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=tpos, lda2=D, a2_rows=Fk)
+                        segs = [(w[pre + "qk.w"], w[pre + "qk.b"], qk, 2 * D, 2 * D, True, ops.FR_NONE),
+                                (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)]
+                        if ftf_fuse_ln:  # token <- norm1(token) in this launch's prologue
+                            FR(token, R, D, segs, a2=tpos, lda2=D, a2_rows=Fk, ln_in=(w[fp + "norm1.weight"], w[fp + "norm1.bias"]),
+                               xn_out=token_alt)
+                            token, token_alt = token_alt, token
+                            tap(f"L{i}.token1", token)
+                        else:
+                            FR(token, R, D, segs, a2=tpos, lda2=D, a2_rows=Fk)
                     else:
                         fk_v = _Fork(tok_stream)
                         with fk_v:
@@ -546,15 +564,24 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     else:
                         gemm_ex(att, w[pre + "out_proj.weight"], token, R, D, D, D, D, D, bias=w[pre + "out_proj.bias"],
                                 res=token, ldres=D, res_mode=RES_ADD)
-                    ln_(token, fp + "norm2")
-                tap(f"L{i}.token2", token)
+                    if not ftf_fuse_ln:
+                        ln_(token, fp + "norm2")
+                if not ftf_fuse_ln:
+                    tap(f"L{i}.token2", token)
                 # (3) every pixel attends to the F tokens of its own frame (:480-484)
                 pre = fp + "frame_token_atten."
                 k = A(R, D)
                 if few(R, "ftf3"):
                     v = A(R, D)
-                    FR(token, R, D, [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, ops.FR_NONE),
-                                     (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)], a2=tpos, lda2=D, a2_rows=Fk)
+                    segs = [(w[pre + "k.w"], w[pre + "k.b"], k, D, D, True, ops.FR_NONE),
+                            (w[pre + "v.w"], w[pre + "v.b"], v, D, D, False, ops.FR_NONE)]
+                    if ftf_fuse_ln and "ftf_tok" not in ABLATE:  # token <- norm2(token) in this launch's prologue
+                        FR(token, R, D, segs, a2=tpos, lda2=D, a2_rows=Fk, ln_in=(w[fp + "norm2.weight"], w[fp + "norm2.bias"]),
+                           xn_out=token_alt)
+                        token, token_alt = token_alt, token
+                        tap(f"L{i}.token2", token)
+                    else:
+                        FR(token, R, D, segs, a2=tpos, lda2=D, a2_rows=Fk)
                 else:
                     fk_v = _Fork(tok_stream)
                     with fk_v:

@@ -1301,6 +1301,24 @@ def test_fewrow_linear(ops, R, K):
     from tce_rvos_amd._lib import TceError
     with pytest.raises(TceError):   # an output on top of the rows other workgroups still read
         ops.fewrow_linear(dx, R, K, [(dev(torch.randn(K, K)), None, dx, K, K, False, ops.FR_NONE)])
+    if K == 256:
+        # LayerNorm PROLOGUE (round 5): the rows are normalised before the addend and the projections, and written out once
+        ga, be = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+        xs = x * 3.0 + 0.7                                  # not already normalised
+        xn = F.layer_norm(xs, (K,), ga, be, 1e-5)
+        o1.fill_(float("nan")); o3.fill_(float("nan"))
+        xn_out = torch.full((R, K), float("nan"), device="cuda")
+        ops.fewrow_linear(dev(xs), R, K, [(dev(w1), dev(b1), o1, 384, 384, True, ops.FR_NONE), (dev(w3), None, o3, 300, 300, False, ops.FR_RELU)],
+                          a2=dpos, lda2=K, a2_rows=8, ln_in=(dev(ga), dev(be)), xn_out=xn_out)
+        close(xn_out, xn, 2e-5, 2e-5)
+        close(o1, F.linear(xn + pos[torch.arange(R) % 8], w1, b1), 5e-5, 5e-5)
+        close(o3, F.relu(F.linear(xn, w3)), 5e-5, 5e-5)
+        with pytest.raises(TceError):   # the normalised copy on top of the rows other workgroups still read
+            dxs = dev(xs)
+            ops.fewrow_linear(dxs, R, K, [(dev(w1), dev(b1), o1, 384, 384, False, ops.FR_NONE)], ln_in=(dev(ga), dev(be)), xn_out=dxs)
+    else:
+        with pytest.raises(TceError):   # the prologue needs the whole row staged at once (K = 256)
+            ops.fewrow_linear(dx, R, K, [(dev(w1), dev(b1), o1, 384, 384, False, ops.FR_NONE)], ln_in=(dev(torch.ones(K)), dev(torch.zeros(K))))
 
 
 @pytest.mark.parametrize("M,N,K,splits,res", [(32, 768, 3072, 16, True), (25, 256, 2048, 8, True), (1, 768, 768, 4, False),
