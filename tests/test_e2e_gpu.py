@@ -503,7 +503,10 @@ def test_two_rank_gloo_rehearsal_on_one_device(group):
                    TCE_BENCH_ONE_DEVICE="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
                                        "--steps", "4", "--warmup", "2", "--frames", "2", "--height", "96", "--width", "128",
-                                       "--tokens", "8", "--no-cpu-baseline", "--no-roofline", "--no-variants", "--group", str(group)],
+                                       "--tokens", "8", "--no-cpu-baseline", "--no-roofline", "--group", str(group)] +
+                                      # group 1 runs WITH the N > 1 variants (the driver's scaling run does): every rank then also times
+                                      # 8 clips per forward, gather included, and the line carries value_group8
+                                      (["--no-variants"] if group > 1 else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
@@ -512,6 +515,10 @@ def test_two_rank_gloo_rehearsal_on_one_device(group):
     assert line["collective"]["gathered_shape"][0] == 2 * group and line["collective"]["own_block_matches"]
     assert "all_gather(uint8 masks)" in line["config"]["parallelism"]
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
+    if group == 1:
+        assert line["value_group8"] > 0 and line["config"]["clips_per_forward"] == 1   # the default line stays G = 1
+    else:
+        assert max(line["group_first_clip_vs_b1_max_rel_err"].values()) <= 2e-5
 
 
 def test_config4_per_rank_shape_through_the_two_rank_flow():
