@@ -703,6 +703,8 @@ class ReferFormer(nn.Module):
         img_h, img_w = float(size[0]), float(size[1])
         if any((float(t["size"][0]), float(t["size"][1])) != (img_h, img_w) for t in targets[1:]):
             raise ValueError("clip groups: the clips of a group share one target size")
+        if any("valid_indices" in t for t in targets):
+            raise NotImplementedError("clip groups: the single-frame path (targets[i]['valid_indices']) runs through forward(), one clip at a time")
         self._ensure_packed()
         ops.range_poll(clips[0].device)
         Tc = shp[0]

@@ -42,7 +42,8 @@ for _ in range(4):
     for c in clips:
         run(c)
 torch.cuda.synchronize()
-assert model.graph_state()["captured"] >= 1, model.graph_state()
+st_ = model.graph_state()
+assert st_["captured"] + st_["owned_alive"] >= 1, st_
 bad = 0
 for r in range(a.reps):
     for c, e in zip(clips, eager):  # alternate two clips so that a replay never sees its own previous input
