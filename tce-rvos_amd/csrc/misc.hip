@@ -453,8 +453,8 @@ __global__ void __launch_bounds__(256) contrastive_final_kernel(const float* __r
     const float dot = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float n1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float n2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-    // ATen cosine_similarity: x.y / sqrt(clamp(|x|^2 |y|^2, eps^2))
-    out[t] = dot / sqrtf(fmaxf(n1 * n2, eps * eps));
+    // ATen cosine_similarity (PyTorch 2.x): each norm clamped separately, x.y / (max(|x|, eps) max(|y|, eps))
+    out[t] = dot / (fmaxf(sqrtf(n1), eps) * fmaxf(sqrtf(n2), eps));
   }
 }
 }  // namespace

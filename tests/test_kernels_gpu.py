@@ -558,6 +558,22 @@ def test_msda_fewq_raw_sample_then_project(ops, N, Lq, ref_dim, padded):
     assert float((old - out).abs().max()) <= 2e-5 * float(expect.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("T,S,fpc", [(3, 168, 3), (5, 4820, 5), (8, 1000, 2), (1, 7, 1)])
+def test_contrastive_cosine(ops, T, S, fpc):
+    """tce_contrastive_f32 (contrastive_cal, tce_rvos.py:512-521): cosine similarity between the mean of a frame's memory rows and
+    its clip's sentence feature, against torch's F.cosine_similarity in fp64 -- several clips per launch (frames_per_clip), row
+    counts that do not divide into the 32 chunks, a near-zero sentence feature (the eps clamp)."""
+    g = torch.Generator().manual_seed(T * S)
+    mem = torch.randn(T, S, 256, generator=g) + 0.3
+    sent = torch.randn(T // fpc, 256, generator=g)
+    if T == 8:
+        sent[1] *= 1e-9   # |x| |y| below eps: the clamp decides
+    out, ws = torch.empty(T, device="cuda"), torch.empty(T * 32 * 256, device="cuda")
+    ops.contrastive(dev(mem), dev(sent), T, S, 256, fpc, out, ws)
+    ref = F.cosine_similarity(mem.double().mean(1), sent.double().repeat_interleave(fpc, 0), dim=1, eps=1e-6)
+    close(out, ref.float(), 1e-5, 1e-6)
+
+
 def test_pos_sine2d(ops):
     for T, h, w in [(2, 9, 13), (1, 45, 80)]:
         ref = O.pos_sine_2d(torch.zeros(T, h, w, dtype=torch.bool), 128).permute(0, 2, 3, 1).reshape(T * h * w, 256)
