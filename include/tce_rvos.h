@@ -405,6 +405,25 @@ typedef struct {
 int tce_xattn_prepare_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, float* W1, float* b1,
                           float* W2, int32_t L, int32_t group, int32_t batch, tceStream stream);
 int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream);
+
+/* Cross-attention -> FFN as ONE launch (round 5): the attention stage exactly as tce_xattn_fused_f32 (its LayerNorm'ed result y is
+ * written to `mid`), then, with y still in registers,  out = LN2( y + W2 relu(W1 y + b1) + b2 )  -- multihead_attn + norm2 +
+ * linear1/ReLU/linear2 + norm3 of a VisionLanguageBlock (segmentation.py:366-377) or frame_token_atten + norm3 + FFN + norm4 of a
+ * FrameTokenLayer (tce_deformable_transformer.py:480-491) without the second launch's row load / the first's row store latency.
+ * args->out receives the FFN's result (may alias args->x); `packed` comes from tce_ffn_pack_chain_f32 (same bytes as
+ * tce_ffn_pack_f32, W1 in the k order of the accumulator registers); mid [rows, 256] must be a buffer of its own. */
+typedef struct {
+  const void* packed;  /* tce_ffn_pack_chain_f32(W1 [hidden,256], b1, W2 [256,hidden]) */
+  const float* b2;     /* [256] */
+  const float* g_out;  /* LayerNorm after the FFN (gamma, beta) or NULL */
+  const float* be_out;
+  float* mid;          /* [rows, 256] per batch entry: the attention stage's result */
+  int64_t ldmid, sMid; /* row pitch / batch stride of mid, in floats */
+  int32_t hidden, act; /* FFN width (multiple of 32), activation (1 = ReLU) */
+  float eps_out;
+} tceXattnFfnArgs;
+int tce_ffn_pack_chain_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd, tceStream stream);
+int tce_xattn_ffn_fused_f32(const tceXattnArgs* args, const tceXattnFfnArgs* ffn, tceStream stream);
 /* tce_xattn_prepare_f32 + tce_ffn_pack_batched_f32 in ONE launch: k, v [batch][L,256] -> `batch` contiguous weight streams of
  * tce_ffn_packed_bytes(256, 8*group) bytes each, bit-identical to the two-launch form. */
 int tce_xattn_pack_f32(const float* k, const float* v, const float* wqT_ext, const float* wo, void* packed, int32_t L, int32_t group,

@@ -41,6 +41,11 @@ class XattnArgs(C.Structure):
 
 
 
+class XattnFfnArgs(C.Structure):
+    _fields_ = [("packed", c_f), ("b2", c_f), ("g_out", c_f), ("be_out", c_f), ("mid", c_f), ("ldmid", i64), ("sMid", i64),
+                ("hidden", i32), ("act", i32), ("eps_out", f32)]
+
+
 class FewRowSeg(C.Structure):
     _fields_ = [("W", c_f), ("bias", c_f), ("out", c_f), ("N", i32), ("ldw", i32), ("ldo", i32), ("use_a2", i32), ("act", i32)]
 
@@ -114,6 +119,8 @@ SIGNATURES = {
     "tce_xattn_prepare_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_ffn_pack_batched_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_xattn_fused_f32": (i32, [C.POINTER(XattnArgs), c_f]),
+    "tce_xattn_ffn_fused_f32": (i32, [C.POINTER(XattnArgs), C.POINTER(XattnFfnArgs), c_f]),
+    "tce_ffn_pack_chain_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tce_xattn_pack_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_rowlin_packed_bytes": (i64, [i32, i32]),
     "tce_rowlin_pack_f32": (i32, [c_f, i64, c_f, i32, i32, c_f]),

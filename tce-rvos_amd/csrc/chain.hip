@@ -265,13 +265,24 @@ struct FfnArgs {
   int* range_flag;  // tce_set_range_flag: set when a hidden or an output value leaves the fp16 range of the split
   int single;       // tce_set_gemm_mode(2): one MFMA per product on nearest-rounded fp16 operands
   int wdiv;         // batch entries (grid.y) sharing one weight stream: stream index = blockIdx.y / wdiv (>= 1)
+  // second stage of a CHAIN (ACT2 != 0, round 5): this kernel's result y (after its LayerNorm) is written to `mid` and, still in
+  // registers, becomes the input of an FFN  out = LN2(y + W2' act2(W1' y + b1') + b2')  -- cross-attention -> FFN of a
+  // VisionLanguageBlock / a FrameTokenLayer as ONE launch.  wpk2: stream packed with tce_ffn_pack_chain_f32 (W1' in the k order
+  // of the accumulator registers); mid must not alias x / res / out of stage 1 that other lanes still read (it is only written
+  // and re-read by the lane that owns the rows).
+  const unsigned char* wpk2;
+  const float *b22, *g_out2, *be_out2;
+  float* mid;
+  long long ldmid, sMid;
+  int NI2;
+  float eps_out2;
 };
 
 // SINGLE (the arithmetic mode, FfnArgs.single at the launch) is a COMPILE-TIME parameter: as a run-time flag it put one uniform
 // branch in front of every step's two lo-term MFMAs (and around every hi / lo split), and the basic-block boundaries kept the
 // scheduler from overlapping a step's loads, DMA and split with its MFMAs: 192 -> 175 us at 24100 rows, 90 -> 79 us for the
 // C = 192 instantiation, the config-2 clip 6.87 -> 6.63 ms (A/B in one call, profiles/r04_single_template.txt).
-template <int C, int WAVES, int ACT, bool SINGLE>
+template <int C, int WAVES, int ACT, bool SINGLE, int ACT2 = 0>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const FfnArgs p) {
   constexpr int KS = C / 16, NT = C / 32;
   constexpr int SLOTS = (1 + 2 * KS + 4 * NT + WAVES - 1) / WAVES;
@@ -303,7 +314,18 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   const unsigned voff = lane * 16;
   const unsigned wbase = wave * PIECE;
   auto dma = [&](int stage, int q) {
-    glds16(wp, voff, wbase + (unsigned)(stage * STAGE + q * WAVES * PIECE));
+    const unsigned char* src = wp;
+    if constexpr (ACT2 != 0) {
+      // the chain switches `wp` to the second stream inside run-time loops: tell the compiler it is still wave-uniform (the DMA's
+      // base is an SGPR pair)
+      const unsigned long long u = (unsigned long long)wp;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+      src = (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+      glds16(src, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(wbase + (unsigned)(stage * STAGE + q * WAVES * PIECE))));
+      wp += WAVES * PIECE;
+      return;
+    }
+    glds16(src, voff, wbase + (unsigned)(stage * STAGE + q * WAVES * PIECE));
     wp += WAVES * PIECE;
   };
 #pragma unroll
@@ -335,7 +357,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 
   // piece index of step `st` (0..STEPS-1) inside a stage: hi piece; the lo piece follows it
   auto piece_of = [](int st) { return 1 + 2 * st; };
-  auto body = [&](auto stage_c) {
+  auto body = [&](auto stage_c, auto act_c) {
+    constexpr int A_ = decltype(act_c)::value;  // this stage's activation (the second stage of a chain runs ACT2)
     constexpr int SB = decltype(stage_c)::value * STAGE;
     const unsigned char* const st = smem + SB + lane * 16;
     f32x16 hacc;
@@ -382,7 +405,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
           }
           oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, hh0, oacc[t], 0, 0, 0);
         }
-        if (ACT == 3 && j == 0) {
+        if (A_ == 3 && j == 0) {
           // "activation" = softmax over the chunk's 32 rows (the 32 keys of one attention head) per token: 16 of them
           // in this lane's registers, 16 in lane ^ 32.  In place; the pair loop below then only splits.
           float mx = hacc[0];
@@ -400,7 +423,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
           for (int i = 0; i < 16; ++i) hacc[i] *= inv;
         }
-        if (ACT == 4 && j == 0) {
+        if (A_ == 4 && j == 0) {
           // 8 keys per head, four heads per chunk: head g of the chunk = rows 8g..8g+7 = registers 4g..4g+3 of this lane
           // (rows 8g + 4hf + 0..3) and of lane ^ 32
 #pragma unroll
@@ -423,11 +446,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
         for (int q = (8 * j) / (2 * NT); q < (8 * (j + 1)) / (2 * NT); ++q) {
           float v0 = hacc[2 * q], v1 = hacc[2 * q + 1];
-          if (ACT == 1) {  // plain v_max: fmaxf() would first quiet a possible sNaN with a second v_max per value
+          if (A_ == 1) {  // plain v_max: fmaxf() would first quiet a possible sNaN with a second v_max per value
             asm("v_max_f32_e32 %0, 0, %1" : "=v"(v0) : "v"(v0));
             asm("v_max_f32_e32 %0, 0, %1" : "=v"(v1) : "v"(v1));
           }
-          if (ACT == 2) {
+          if (A_ == 2) {
             v0 = tce_gelu(v0);
             v1 = tce_gelu(v1);
           }
@@ -456,12 +479,63 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
     }
   };
   if (stamps) stamps[1] = (long long)__builtin_amdgcn_s_memtime();
-  int it = 0;
-  for (; it + 1 < p.NI; it += 2) {
-    body(std::integral_constant<int, 0>{});
-    body(std::integral_constant<int, 1>{});
+  using act1_t = std::integral_constant<int, ACT>;
+  if constexpr (ACT2 == 0) {
+    int it = 0;
+    for (; it + 1 < p.NI; it += 2) {
+      body(std::integral_constant<int, 0>{}, act1_t{});
+      body(std::integral_constant<int, 1>{}, act1_t{});
+    }
+    if (it < p.NI) body(std::integral_constant<int, 0>{}, act1_t{});
+  } else {
+    // ---- chain: stage 1, its epilogue into `mid` and into the operand registers, stage 2.  The ring parity is a run-time value
+    // here (one uniform branch per iteration of 96 MFMAs).
+    int par = 0;
+    auto run = [&](const int n, auto act_c) {
+      for (int i = 0; i < n; ++i) {
+        if (par == 0) body(std::integral_constant<int, 0>{}, act_c);
+        else body(std::integral_constant<int, 1>{}, act_c);
+        par ^= 1;
+      }
+    };
+    run(p.NI - 1, act1_t{});
+    wp = p.wpk2 + (long long)wave * PIECE;  // the last iteration of stage 1 prefetches block 0 of stage 2's stream
+    run(1, act1_t{});
+    {
+      float* const midb = p.mid + blockIdx.y * p.sMid;
+      ResTile rt[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(resb, ldres, m0, p.M, 32 * t, lane);
+      if (p.res_mode == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile_bias_res<2>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
+      }
+      if (p.g_out) rows_layernorm<NT>(oacc, p.g_out, p.be_out, p.eps_out, hf);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tile_store(oacc[t], midb, p.ldmid, m0, p.M, 32 * t, wt, lane, amax);
+      // y (accumulator layout: lane = token, registers 4g..4g+3 of tile t = channels 32t + 8g + 4hf + 0..3) IS a B operand in
+      // the k order  16s + 8(j>>2) + 4hf + (j&3)  -- the order stage 2's W1 fragments are packed in (tce_ffn_pack_chain_f32)
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const int t = s2 >> 1, g0 = 2 * (s2 & 1);
+        const float f[8] = {oacc[t][4 * g0], oacc[t][4 * g0 + 1], oacc[t][4 * g0 + 2], oacc[t][4 * g0 + 3],
+                            oacc[t][4 * g0 + 4], oacc[t][4 * g0 + 5], oacc[t][4 * g0 + 6], oacc[t][4 * g0 + 7]};
+        const HL sp = split8(f, single);
+        xh[s2] = sp.hi;
+        xl[s2] = sp.lo;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hh0[j] = hl0[j] = hh1[j] = hl1[j] = (_Float16)0.f;
+    }
+    run(p.NI2, std::integral_constant<int, ACT2>{});
   }
-  if (it < p.NI) body(std::integral_constant<int, 0>{});
   if (FFN_ABL & 3) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -470,7 +544,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 
   // ---- epilogue: + b2 + residual, optional LayerNorm, stores -- all global traffic in full lines through the wave's
   // staging tile
-  {
+  if constexpr (ACT2 != 0) {  // stage 2 of a chain: residual = this lane's own rows of `mid`, additive; stage 2's bias / LayerNorm
+    const float* const midb = p.mid + blockIdx.y * p.sMid;
+    ResTile rt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(midb, p.ldmid, m0, p.M, 32 * t, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b22, 32 * t, lane), rt[t], wt, lane);
+    if (p.g_out2) rows_layernorm<NT>(oacc, p.g_out2, p.be_out2, p.eps_out2, hf);
+  } else {
     ResTile rt[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) rt[t] = tile_res_load(resb, ldres, m0, p.M, 32 * t, lane);
@@ -481,8 +563,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 #pragma unroll
       for (int t = 0; t < NT; ++t) tile_bias_res<1>(oacc[t], tile_bias_load(p.b2, 32 * t, lane), rt[t], wt, lane);
     }
+    if (p.g_out) rows_layernorm<NT>(oacc, p.g_out, p.be_out, p.eps_out, hf);
   }
-  if (p.g_out) rows_layernorm<NT>(oacc, p.g_out, p.be_out, p.eps_out, hf);
 #pragma unroll
   for (int t = 0; t < NT; ++t) tile_store(oacc[t], outb, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
   tce_range_report(p.range_flag, amax);
@@ -497,7 +579,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
 __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, unsigned char* __restrict__ out,
                                                        const int C, const int Hd, const int P,
-                                                       const long long units, const int single) {
+                                                       const long long units, const int single, const int permk = 0) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= units) return;
   W1 += (long long)blockIdx.y * Hd * C;  // batch entries: contiguous [Hd,C], [Hd], [C,Hd] blocks, contiguous streams
@@ -527,7 +609,12 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
       const int s = (piece - 1) >> 1;
       plane = (piece - 1) & 1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = it < NC ? W1[(long long)(32 * it + r) * C + 16 * s + 8 * hf + j] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        // permk (second stage of a chain): the x operand is the previous stage's accumulator, whose registers enumerate a
+        // k-step's 16 channels as 8(j>>2) + 4hf + (j&3) -- W1 follows that order (like W2 does for the hidden units below)
+        const int kk = permk ? 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3) : 16 * s + 8 * hf + j;
+        v[j] = it < NC ? W1[(long long)(32 * it + r) * C + kk] : 0.f;
+      }
     } else {
       const int q = piece - 1 - 2 * KS;
       plane = q & 1;
@@ -1394,6 +1481,17 @@ extern "C" int tce_ffn_pack_batched_f32(const float* W1, const float* b1, const 
   return TCE_OK;
 }
 
+extern "C" int tce_ffn_pack_chain_f32(const float* W1, const float* b1, const float* W2, void* packed, int32_t C, int32_t Hd,
+                                      tceStream stream) {
+  TCE_CHECK_ARG(C == 256 && ffn_shape_ok(C, Hd), "tce_ffn_pack_chain_f32: C must be 256, hidden %% 32 == 0 (C=%d hidden=%d)", C, Hd);
+  TCE_CHECK_ARG(W1 && W2 && packed && tce_aligned16(packed), "tce_ffn_pack_chain_f32: null / misaligned pointer");
+  const long long units = ffn_units(C, Hd);
+  hipLaunchKernelGGL(ffn_pack_kernel, dim3(tce_cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, W1, b1, W2,
+                     (unsigned char*)packed, C, Hd, ffn_pieces(C), units, tce_gemm_single_pass(), 1);
+  TCE_CHECK_LAUNCH("tce_ffn_pack_chain_f32");
+  return TCE_OK;
+}
+
 extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in,
                                  const float* be_in, float eps_in, const float* g_out, const float* be_out,
                                  float eps_out, float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act,
@@ -1451,7 +1549,26 @@ extern "C" int tce_xattn_pack_f32(const float* k, const float* v, const float* w
   return TCE_OK;
 }
 
-extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
+static int xattn_launch(const tceXattnArgs* args, const tceXattnFfnArgs* ffn, tceStream stream);
+
+extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) { return xattn_launch(args, nullptr, stream); }
+
+// cross-attention -> FFN as ONE launch (round 5): see tceXattnFfnArgs in the header
+extern "C" int tce_xattn_ffn_fused_f32(const tceXattnArgs* args, const tceXattnFfnArgs* ffn, tceStream stream) {
+  TCE_CHECK_ARG(args && ffn, "tce_xattn_ffn_fused_f32: null args");
+  TCE_CHECK_ARG(ffn->packed && ffn->b2 && ffn->mid && ffn->hidden > 0 && ffn->hidden % 32 == 0 && ffn_shape_ok(256, ffn->hidden),
+                "tce_xattn_ffn_fused_f32: bad FFN stage (packed / b2 / mid / hidden)");
+  TCE_CHECK_ARG(ffn->act == 1, "tce_xattn_ffn_fused_f32: the FFN stage's activation must be 1 (ReLU)");
+  TCE_CHECK_ARG(ffn->ldmid >= 256 && ffn->ldmid % 4 == 0 && ffn->sMid % 4 == 0 && tce_aligned16(ffn->mid) && tce_aligned16(ffn->packed) &&
+                    tce_aligned16(ffn->b2) && (!ffn->g_out || (ffn->be_out && tce_aligned16(ffn->g_out) && tce_aligned16(ffn->be_out))),
+                "tce_xattn_ffn_fused_f32: FFN stage pitch / alignment");
+  TCE_CHECK_ARG(args->res_mode == 1, "tce_xattn_ffn_fused_f32: the attention stage's residual must be additive");
+  TCE_CHECK_ARG(ffn->mid != args->x && ffn->mid != args->out && ffn->mid != args->res,
+                "tce_xattn_ffn_fused_f32: mid must be a buffer of its own (it is written and re-read inside the launch)");
+  return xattn_launch(args, ffn, stream);
+}
+
+static int xattn_launch(const tceXattnArgs* args, const tceXattnFfnArgs* ffn, tceStream stream) {
   TCE_CHECK_ARG(args != nullptr, "tce_xattn_fused_f32: null args");
   const tceXattnArgs& q = *args;
   TCE_CHECK_ARG(q.M > 0 && q.x && q.packed && q.bo && q.out, "tce_xattn_fused_f32: null pointer or M <= 0");
@@ -1473,6 +1590,19 @@ extern "C" int tce_xattn_fused_f32(const tceXattnArgs* args, tceStream stream) {
   a.wdiv = q.w_div > 0 ? q.w_div : 1;
   const int batch = q.batch > 0 ? q.batch : 1;
   const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
+  if (ffn) {
+    a.wpk2 = (const unsigned char*)ffn->packed; a.b22 = ffn->b2; a.g_out2 = ffn->g_out; a.be_out2 = ffn->be_out; a.eps_out2 = ffn->eps_out;
+    a.mid = ffn->mid; a.ldmid = ffn->ldmid; a.sMid = ffn->sMid; a.NI2 = ffn->hidden / 32 + 1;
+    if (a.single) {
+      if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3, true, 1>), grid, block, 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4, true, 1>), grid, block, 0, (hipStream_t)stream, a);
+    } else {
+      if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3, false, 1>), grid, block, 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4, false, 1>), grid, block, 0, (hipStream_t)stream, a);
+    }
+    TCE_CHECK_LAUNCH("tce_xattn_ffn_fused_f32");
+    return TCE_OK;
+  }
   if (a.single) {
     if (q.group == 32) hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 3, true>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((ffn_fused_kernel<256, 4, 4, true>), grid, block, 0, (hipStream_t)stream, a);

@@ -159,6 +159,18 @@ def _xattn(q):
     return rd, [strided(_p(q.out), 256 * F, (b, q.sOut * F), (q.M, q.ldo * F))]
 
 
+def _xattn_ffn(q, f):
+    """the chain launch: the attention stage's accesses + the FFN stage's stream / bias / LayerNorm; `mid` is written and re-read"""
+    rd, wr = _xattn(q)
+    b = max(1, q.batch)
+    rd += [dense(_p(f.packed), _lib.lib_raw().tce_ffn_packed_bytes(256, f.hidden)), dense(_p(f.b2), 256 * F)]
+    for g_ in (f.g_out, f.be_out):
+        if g_:
+            rd.append(dense(_p(g_), 256 * F))
+    wr.append(strided(_p(f.mid), 256 * F, (b, f.sMid * F), (q.M, f.ldmid * F)))
+    return rd, wr
+
+
 def _fewrow(q):
     rd = [strided(_p(q.x), q.K * F, (q.R, q.ldx * F))]
     wr = []
@@ -340,6 +352,8 @@ MODELS = {
          dense(_p(a[3]), 256 * 256 * F)],
         [dense(_p(a[4]), a[9] * 8 * a[8] * 256 * F), dense(_p(a[5]), a[9] * 8 * a[8] * F), dense(_p(a[6]), a[9] * 8 * a[8] * 256 * F)]),
     "tce_xattn_fused_f32": lambda a: _xattn(_st(a[0])),
+    "tce_xattn_ffn_fused_f32": lambda a: _xattn_ffn(_st(a[0]), _st(a[1])),
+    "tce_ffn_pack_chain_f32": lambda a: _ffn_pack(a, False),
     # k, v, wqT, wo, packed, L, group, batch
     "tce_xattn_pack_f32": lambda a: (
         [dense(_p(a[0]), a[7] * a[5] * 256 * F), dense(_p(a[1]), a[7] * a[5] * 256 * F), dense(_p(a[2]), 257 * 256 * F), dense(_p(a[3]), 256 * 256 * F)],

@@ -445,6 +445,12 @@ class ReferFormer(nn.Module):
                             mode = self.mode_of(arith_group_of(pre + tag))
                             with ops.arith(mode):
                                 w[pre + tag + ":" + mode] = ops.ffn_pack(w1, sd[pre + l1[:-len("weight")] + "bias"].detach(), w2)
+                                # FFNs that directly follow a folded cross-attention launch (the frame-token layers' pixel FFN, the
+                                # pixel decoder's VisionLanguageBlocks): the W1 stream in the k order of the attention kernel's
+                                # accumulator registers, for the one-launch chain -- only where both site groups run one arithmetic
+                                xg = ("encoder.ftf_x" if ".ftoken_layers." in pre else "pixel.xattn" if ".cross_attn_" in pre else None)
+                                if xg is not None and tag == ".ffn:pk" and ops.XATTN_FFN_CHAIN and self.mode_of(xg) == mode:
+                                    w[pre + ".ffn:pkc:" + mode] = ops.ffn_pack_chain(w1, sd[pre + ".linear1.bias"].detach(), w2)
             # Swin attention half-block as one launch (csrc/swinattn.hip): per block, Wqkv | Wproj as one fragment stream
             if not cfg.is_resnet and not cfg.video and self._stamp[0] != "f32":
                 mode = self.mode_of("backbone.attn")

@@ -1133,10 +1133,34 @@ def xattn_pack(k, v, wqT_ext, wo, L, alloc, group=32, batch=1):
     return pk
 
 
+# cross-attention and the FFN behind it as ONE launch (tce_xattn_ffn_fused_f32).  Built and measured in round 5: correct (kernel and
+# whole-clip parity green with it on) but not faster -- config 2 B=1 6.37 / 6.41 ms with it against 6.29 / 6.36 ms without, G=8 37.5
+# against 36.8 ms (profiles/r05_round_ab.txt): the launch saved and the [M, 256] re-read avoided (~5 us a site) are less than what
+# the second stage loses to the chain kernel's register pressure (50 spilled VGPRs outside the loops, one resident workgroup).  Off.
+XATTN_FFN_CHAIN = os.environ.get("TCE_XATTN_FFN_CHAIN", "0") != "0"
+
+
+def ffn_pack_chain(w1, b1, w2):
+    """FFN stream for the SECOND stage of a cross-attention -> FFN chain launch (tce_ffn_pack_chain_f32: W1 in the k order of the
+    accumulator registers; C = 256)."""
+    _chk(w1, "w1")
+    _chk(w2, "w2")
+    Hd, Cn = w1.shape
+    nbytes = lib().tce_ffn_packed_bytes(Cn, Hd)
+    if Cn != 256 or nbytes < 0 or tuple(w2.shape) != (Cn, Hd):
+        raise ValueError(f"ffn_pack_chain: unsupported shape C={Cn} hidden={Hd}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    check(lib().tce_ffn_pack_chain_f32(w1.contiguous().data_ptr(), b1.contiguous().data_ptr() if b1 is not None else None,
+                                       w2.contiguous().data_ptr(), out.data_ptr(), Cn, Hd, _stream()), "tce_ffn_pack_chain_f32")
+    return out
+
+
 def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_mode=RES_ADD, ln_out=None, eps_out=1e-5,
-                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256, group=32, per_batch_weights=False, w_div=1):
-    """w_div: batch entries that share one weight stream (entry b reads stream b // w_div; per_batch_weights only)."""
-    from ._lib import XattnArgs
+                batch=1, sX=0, sRes=0, sOut=0, ldx=256, ldo=256, ldres=256, group=32, per_batch_weights=False, w_div=1, ffn=None):
+    """w_div: batch entries that share one weight stream (entry b reads stream b // w_div; per_batch_weights only).
+    ffn = (chain-packed stream, b2, hidden, (gamma, beta) or None, mid tensor, sMid): the FFN that follows runs in the SAME launch
+    (tce_xattn_ffn_fused_f32): `out` receives LN(y + FFN(y)), `mid` [rows, 256] the attention stage's y."""
+    from ._lib import XattnArgs, XattnFfnArgs
     q = XattnArgs()
     q.x, q.packed, q.bo, q.out = x.data_ptr(), pk.data_ptr(), bo.data_ptr(), out.data_ptr()
     q.M, q.batch, q.res_mode, q.eps_out, q.group = M, batch, res_mode, eps_out, group
@@ -1151,8 +1175,19 @@ def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_m
     if ln_out is not None:
         q.g_out, q.be_out = ln_out[0].data_ptr(), ln_out[1].data_ptr()
 
+    fq = None
+    if ffn is not None:
+        pk2, b2, hidden, ln2, mid, s_mid = ffn
+        fq = XattnFfnArgs()
+        fq.packed, fq.b2, fq.mid, fq.ldmid, fq.sMid, fq.hidden, fq.act = pk2.data_ptr(), b2.data_ptr(), mid.data_ptr(), 256, s_mid, hidden, 1
+        if ln2 is not None:
+            fq.g_out, fq.be_out, fq.eps_out = ln2[0].data_ptr(), ln2[1].data_ptr(), 1e-5
+
     def go():
-        check(lib().tce_xattn_fused_f32(C.byref(q), _stream()), "tce_xattn_fused_f32")
+        if fq is not None:
+            check(lib().tce_xattn_ffn_fused_f32(C.byref(q), C.byref(fq), _stream()), "tce_xattn_ffn_fused_f32")
+        else:
+            check(lib().tce_xattn_fused_f32(C.byref(q), _stream()), "tce_xattn_fused_f32")
     if GEMM_PROFILE is None:
         go()
         return out
@@ -1160,7 +1195,10 @@ def xattn_fused(x, pk, bo, M, out, a2=None, lda2=256, a2_rows=0, res=None, res_m
     e0.record()
     go()
     e1.record()
-    GEMM_PROFILE.append(("xattn(ffn_fused_kernel<256,4,3|4>", False, 4.0 * M * 256 * 8 * group * batch, e0, e1))
+    if fq is not None:
+        GEMM_PROFILE.append(("xattn+ffn(ffn_fused_kernel<256,4,3|4,1>", False, 4.0 * M * 256 * (8 * group + hidden) * batch, e0, e1))
+    else:
+        GEMM_PROFILE.append(("xattn(ffn_fused_kernel<256,4,3|4>", False, 4.0 * M * 256 * 8 * group * batch, e0, e1))
     return out
 
 

@@ -284,6 +284,19 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                 ln=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)  # the norm rides in the split-K reduction
         ar.release(m1)
 
+    def chain_ffn(pre, group, M, norm, A, sMid):
+        """The FFN stage of a cross-attention -> FFN chain launch (ops.xattn_fused(ffn=...)), or None where the two run as two
+        launches: the chain needs the chain-ordered W1 stream (model._pack: both site groups in one arithmetic) and the row count
+        of the fused FFN route.  `mid` (the attention stage's rows, the FFN's residual) is scratch of the caller's arena."""
+        if not (ops.XATTN_FFN_CHAIN and fused_ok and M >= FFN_FUSED_MIN_ROWS) or "ffn:" + group in ABLATE:
+            return None
+        pkc = w.get(pre + "ffn:pkc:" + ops.get_gemm_mode())
+        if pkc is None or model.mode_of(group) != ops.get_gemm_mode():
+            return None
+        return (pkc, w[pre + "linear2.bias"], ff, (w[norm + ".weight"], w[norm + ".bias"]), A(M, D), sMid)
+
+    ffn.chain = chain_ffn  # travels with `ffn` into the pixel decoder's branches
+
     # input_proj + early fusion of a level (:258-307) needs that level's backbone map and the text only: with the extra
     # branches of fork3 the two large levels start as soon as their Swin stage is done, beside the later stages (which
     # work on few tokens); the two small ones follow the backbone, each on its own stream.
@@ -591,14 +604,16 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     fk_v.join()
             tap(f"L{i}.k3", k)
             tap(f"L{i}.v3", v)
+            chained = None
             with model.arith("encoder.ftf_x"):
                 if Fk == 8 and fused_ok and T * S >= ops.XATTN_MIN_ROWS:
                     # q-proj -> attention over the frame's 8 tokens -> out-proj -> + src -> norm3 in one token-stationary
                     # launch (the keys / values differ per frame: one folded weight stream per frame)
                     pk = ops.xattn_pack(k, v, w[pre + "q.wT:x"], w[pre + "out_proj.weight"], Fk, A, group=8, batch=T)
+                    chained = chain_ffn(fp, "encoder.ffn", T * S, fp + "norm4", A, S * D)
                     ops.xattn_fused(src, pk, w[pre + "out_proj.bias"], S, src, a2=lvl_pos,
                                     ln_out=(w[fp + "norm3.weight"], w[fp + "norm3.bias"]), batch=T, sX=S * D, sOut=S * D,
-                                    group=8, per_batch_weights=True)
+                                    group=8, per_batch_weights=True, ffn=chained)
                 else:
                     q = A(T * S, D)
                     gemm_ex(src, w[pre + "q.w"], q, S, D, D, D, D, D, bias=w[pre + "q.b"], a2=lvl_pos, lda2=D, batch=T,
@@ -607,10 +622,11 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
                     ops.mha_core(q, k, v, T, NH, S, Fk, D, D, D, S * D, Fk * D, Fk * D, att, D, S * D)
                     _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], src, T * S, w[fp + "norm3.weight"],
                                  w[fp + "norm3.bias"])
+            tap(f"L{i}.src3", src if chained is None else chained[4])
             ar.release(m0)
-            tap(f"L{i}.src3", src)
             # (4) FFN over all pixels (:489-491)
-            ffn(src, T * S, fp, norm=fp + "norm4")
+            if chained is None:
+                ffn(src, T * S, fp, norm=fp + "norm4")
             tap(f"L{i}.src4", src)
         if "enc_msda" not in ABLATE:
             # the offsets|weights projection (src + pos) and the value projection (src) are independent 24100-row GEMMs of 1.1 and
@@ -1025,12 +1041,14 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
         m1 = arx.mark()
         tk, tv, pk = vl_sites[stage]
         Mc = (T // G) * hw  # rows of one clip
+        chained = None
         if pk is not None:
             # q-proj -> attention over the text keys -> out-proj -> + tgt -> norm2 in one token-stationary launch (one batch entry
-            # and one folded weight stream per clip)
+            # and one folded weight stream per clip); with the FFN + norm3 behind it in the same launch where chain_ffn allows
+            chained = ffn.chain(bp, "pixel.ffn", T * hw, bp + "norm3", A, Mc * D)
             ops.xattn_fused(tgt, pk, w[pre + "out_proj.bias"], Mc, tgt, a2=pos, a2_rows=hw,
                             ln_out=(w[bp + "norm2.weight"], w[bp + "norm2.bias"]), batch=G, sX=Mc * D, sOut=Mc * D,
-                            per_batch_weights=G > 1)
+                            per_batch_weights=G > 1, ffn=chained)
         else:
             q = A(T * hw, D)
             gemm_ex(tgt, w[pre + "q.w"], q, hw, D, D, D, D, D, bias=w[pre + "q.b"], a2=pos, lda2=D, batch=T, sA=hw * D,
@@ -1040,7 +1058,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
             _proj_res_ln(att, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], tgt, T * hw, w[bp + "norm2.weight"],
                          w[bp + "norm2.bias"])
         arx.release(m1)
-    ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx, group="pixel.ffn")
+    if chained is None:
+        ffn(tgt, T * hw, bp, norm=bp + "norm3", ar=arx, group="pixel.ffn")
     if _TAP_FN is not None:
         _TAP_FN(f"vl{stage}", tgt)  # the VisionLanguageBlock's output (segmentation.py:326-377)
     return tgt

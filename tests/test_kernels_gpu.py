@@ -1081,6 +1081,46 @@ def test_xattn_fused(ops, M, L, mode):
     close(out, ref, 3e-4, 3e-4)
 
 
+@pytest.mark.parametrize("M,L,group,batch", [(18000, 32, 32, 1), (4820, 8, 8, 5), (301, 11, 32, 1), (130, 8, 8, 3)])
+def test_xattn_ffn_chain_matches_two_launches(ops, M, L, group, batch):
+    """tce_xattn_ffn_fused_f32 (round 5): cross-attention -> LayerNorm -> FFN -> LayerNorm as ONE launch against the two launches
+    it replaces (tce_xattn_fused_f32, then tce_ffn_fused_f32 in place): the attention stage's rows land in `mid` bit-identical,
+    the FFN stage (operand taken from the accumulator registers, W1 packed in their k order) within fp32 round-off of the
+    two-launch result and of torch fp64; per-frame weight streams (group 8, batch = frames) and the text form (group 32); ragged
+    last row block; in place on x."""
+    g = torch.Generator().manual_seed(M + L)
+    Cn, Hd = 256, 2048
+    x = torch.randn(batch * M, Cn, generator=g)
+    pos = torch.randn(M, Cn, generator=g) * 0.5
+    k, v = torch.randn(batch, L, Cn, generator=g), torch.randn(batch, L, Cn, generator=g)
+    Wq, bq = torch.randn(Cn, Cn, generator=g) * 0.06, torch.randn(Cn, generator=g) * 0.2
+    Wo, bo = torch.randn(Cn, Cn, generator=g) * 0.06, torch.randn(Cn, generator=g) * 0.2
+    g1, be1 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    W1, b1 = torch.randn(Hd, Cn, generator=g) / 16, torch.randn(Hd, generator=g) * 0.2
+    W2, b2 = torch.randn(Cn, Hd, generator=g) / 45, torch.randn(Cn, generator=g) * 0.2
+    g2, be2 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    ar = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device="cuda")
+    wqT = ops.xattn_static(dev(Wq), dev(bq))
+    pk = ops.xattn_pack(dev(k), dev(v), wqT, dev(Wo), L, ar, group=group, batch=batch)
+    kw = dict(a2=dev(pos), ln_out=(dev(g1), dev(be1)), batch=batch, sX=M * Cn, sOut=M * Cn, group=group, per_batch_weights=batch > 1)
+    # the two launches
+    y = torch.empty(batch * M, Cn, device="cuda")
+    ops.xattn_fused(dev(x), pk, dev(bo), M, y, **kw)
+    ref2 = y.clone()
+    ops.ffn_fused(ref2, ops.ffn_pack(dev(W1), dev(b1), dev(W2)), dev(b2), Hd, ops.ACT_RELU, ln_out=(dev(g2), dev(be2)))
+    # the chain, in place on x
+    xd, mid = dev(x), torch.full((batch * M, Cn), float("nan"), device="cuda")
+    ops.xattn_fused(xd, pk, dev(bo), M, xd, ffn=(ops.ffn_pack_chain(dev(W1), dev(b1), dev(W2)), dev(b2), Hd, (dev(g2), dev(be2)), mid, M * Cn), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(mid, y)                                   # stage 1 is the same arithmetic
+    scale = float(ref2.abs().max())
+    assert float((xd - ref2).abs().max()) <= 2e-5 * scale        # stage 2: another summation order of the first product only
+    yd = y.double().cpu()
+    ref64 = F.layer_norm(yd + F.linear(F.relu(F.linear(yd, W1.double(), b1.double())), W2.double(), b2.double()), (Cn,), g2.double(), be2.double(), 1e-5)
+    assert float((xd.double().cpu() - ref64).abs().max()) <= 3e-5 * scale
+    ops.check_range()
+
+
 @pytest.mark.parametrize("L,group,batch", [(32, 32, 1), (9, 32, 1), (8, 8, 5), (5, 8, 2)])
 def test_xattn_pack_one_launch_is_bit_identical(ops, L, group, batch):
     """tce_xattn_pack_f32 (fold + pack in one launch) against tce_xattn_prepare_f32 -> tce_ffn_pack_batched_f32: the same bytes."""
