@@ -161,6 +161,9 @@ def main():
 
     from tce_rvos_amd import build_model, ops
     from tce_rvos_amd.dist import gather_clip_masks_async
+    if os.environ.get("TCE_GEMM_TILE_RULES") == "r4":  # A/B aid (tools/runs/): tile selection by the previous round's rules
+        from tce_rvos_amd._lib import lib as _l
+        _l().tce_gemm_force_tile(-1)
     from tce_rvos_amd.model import ARITH_POLICIES
     if args.arith_policy not in ARITH_POLICIES:
         raise SystemExit(f"--arith-policy: unknown policy {args.arith_policy!r}; choose from {sorted(ARITH_POLICIES)}")

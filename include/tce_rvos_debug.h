@@ -6,7 +6,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* tuning aid: force the output tile of the GEMM entry point (0 = automatic) */
+/* tuning aid: force the output tile of the GEMM entry point (0 = automatic; -1 = automatic by the rules of round 4, for A/B) */
 int tce_gemm_force_tile(int32_t tile);
 /* register (or clear with NULL) a device buffer of >= 2048*8 int64 for the split GEMM's in-kernel s_memtime stamps */
 int tce_debug_set_stamp_buffer(long long* dev_buf);

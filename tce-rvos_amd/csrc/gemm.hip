@@ -235,10 +235,12 @@ extern "C" int tce_get_gemm_mode(void) { return g_gemm_mode; }
 // tile choice: the largest tile that still yields >= 2 workgroups per CU; fp32 MFMA is slow enough
 // (64 cycles per 32x32x2) that the smaller tiles' extra LDS traffic is hidden, so favour grid fill.
 static int g_force_tile = 0;
-extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile (tuning aid)
-  TCE_CHECK_ARG(tile == 0 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465,
-                "tce_gemm_force_tile: bad tile (0, 256128, 128128, 12864, 6464 or 6465)");
-  g_force_tile = tile;
+static bool g_rules_r4 = false;
+extern "C" int tce_gemm_force_tile(int32_t tile) {  // 0 = automatic; 128128 / 12864 / 6464 pin the tile; -1 = automatic by round 4's rules (tuning aids)
+  TCE_CHECK_ARG(tile == 0 || tile == -1 || tile == 256128 || tile == 128128 || tile == 12864 || tile == 6464 || tile == 6465,
+                "tce_gemm_force_tile: bad tile (0, -1, 256128, 128128, 12864, 6464 or 6465)");
+  g_force_tile = tile > 0 ? tile : 0;
+  g_rules_r4 = tile == -1;
   return TCE_OK;
 }
 
@@ -254,6 +256,10 @@ static int select_tile_ex(int M, int N, int K, int batch, int conv) {
     // (tools/gemm_shape_sweep.py over every launch of a config-2 clip: deep-K / wide problems already prefer the
     // 8-wave tile at ~0.65 waves of the chip, e.g. 24100x256x2048 90 us vs 100 us, 4600x1536x384 31 us vs 37 us)
     if (!conv && ((n256 >= 384 && N >= 512) || (n256 >= 128 && K >= 1024) || (n256 >= 160 && N >= 1024 && K >= 384))) return 256128;
+    // round 5, the shapes of an 8-clip group and of the 72000-row maps (tools/runs/r6r.sh, every tile forced): 1.5 rounds of the
+    // chip are enough at N = 256 / 384 too (36800x384x384 48.5 vs 54.3 us, 192800x256x256 117 vs 150, 576000x256x96 212 vs 287),
+    // and a square-ish deep problem prefers it from 0.9 rounds (9600x768x768 40.1 vs 52.8); un-batched launches only (what was measured)
+    if (!conv && !g_rules_r4 && b == 1 && ((n256 >= 384 && N >= 256) || (n256 >= 224 && N >= 768 && K >= 768))) return 256128;
     if (conv && n128 >= 256) return 128128;
     if (n12864 >= 384 && M > 64) return 12864;
     // deep K with a moderate grid (Swin stage 3's fc2, 4600 x 384 x 1536: 216 tiles of 128x64): the wider tile halves the
