@@ -330,6 +330,19 @@ int tce_ffn_pack_batched_f32(const float* W1, const float* b1, const float* W2, 
 int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in,
                       const float* be_in, float eps_in, const float* g_out, const float* be_out, float eps_out,
                       float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act, tceStream stream);
+/* The same launch with the hidden extent of a row block cut once and the two pieces on different workgroups (round 5): a workgroup
+ * owns 128 rows and a launch of 24100 rows is 189 of them -- 0.74 rounds of 256 CUs that cost a full one.  With p blocks handed to
+ * p + 1 workgroups a round is ~p/(p+1) as long.  tce_ffn_split_ws_floats > 0 says that a split is planned for the shape (C = 256,
+ * ReLU, where the launcher's model says it pays -- csrc/chain.hip ffn_split_plan, calibrated on measurements) and how many floats of workspace it needs; tce_ffn_split_counters how many int32
+ * counters.  The counters must be ZERO at the launch and are zero again when it ends (a block's second arriver adds the two partial
+ * sums -- the same bits whichever piece arrives last -- runs the epilogue and resets the counter): give each call site that can run
+ * concurrently with another its own.  Results differ from tce_ffn_fused_f32's by fp32 round-off (one more addition per element). */
+int64_t tce_ffn_split_ws_floats(int32_t M, int32_t C, int32_t Hd, int32_t act);
+int32_t tce_ffn_split_counters(int32_t M, int32_t C, int32_t Hd, int32_t act);
+int tce_ffn_fused_split_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in, const float* be_in,
+                            float eps_in, const float* g_out, const float* be_out, float eps_out, float* out, int64_t ldo, int32_t M,
+                            int32_t C, int32_t Hd, int32_t act, float* ws, int64_t ws_floats, int32_t* counters, int32_t n_counters,
+                            tceStream stream);
 
 /* Token-stationary linear layer (csrc/chain.hip), for K in {96,128,192,256,384,512} and many rows:
  *     out[M,N] = LN_out?( epi( LN_in?(x + a2) W^T + bias ) )      epi: act 0 none | 1 ReLU | 2 GELU(erf), then

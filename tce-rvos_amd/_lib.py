@@ -116,6 +116,9 @@ SIGNATURES = {
     "tce_ffn_packed_bytes": (i64, [i32, i32]),
     "tce_ffn_pack_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tce_ffn_fused_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f]),
+    "tce_ffn_split_ws_floats": (i64, [i32, i32, i32, i32]),
+    "tce_ffn_split_counters": (i32, [i32, i32, i32, i32]),
+    "tce_ffn_fused_split_f32": (i32, [c_f, i64, c_f, c_f, c_f, c_f, f32, c_f, c_f, f32, c_f, i64, i32, i32, i32, i32, c_f, i64, c_f, i32, c_f]),
     "tce_xattn_prepare_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_ffn_pack_batched_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_xattn_fused_f32": (i32, [C.POINTER(XattnArgs), c_f]),

@@ -215,6 +215,47 @@ __device__ __forceinline__ void tile_store(const f32x16& acc, float* __restrict_
   __builtin_amdgcn_wave_barrier();
 }
 
+// Partial sums exchanged between two workgroups of one launch (the split FFN): agent-scope accesses (sc1: written through to /
+// read from the memory side of the per-XCD L2s) instead of fences -- an agent-scope release / acquire writes back and INVALIDATES
+// the XCD's whole L2, and with it the weight stream every workgroup of the XCD is reading (measured: the split launch 258 us with
+// __threadfence() against 167 us un-split).  Register order: lane l's f32x4 number j of the wave at ((j * 64) + l) * 16 bytes, so an
+// instruction moves one contiguous KiB and the reader is the same lane of the same wave of the partner workgroup.
+__device__ __forceinline__ void partial_store(const f32x16& acc, float* __restrict__ base, const int t, const int lane) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    float* const ptr = base + ((t * 4 + g) * 64 + lane) * 4;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(o) : "memory");
+  }
+}
+struct PartTile {
+  f32x4 v[4];
+};
+// Four tiles (16 loads, one round trip) per asm statement, the wait INSIDE it: between an asm load and a separate wait the compiler
+// may move the "loaded" registers (copies into AGPRs under this kernel's register pressure) before the data has arrived -- measured:
+// finite garbage in some elements.
+__device__ __forceinline__ void partial_load4(const float* __restrict__ base, const int t0, const int lane, PartTile& a, PartTile& b,
+                                              PartTile& c, PartTile& d) {
+  const float* const pa = base + ((t0 * 4) * 64 + lane) * 4;
+  const float* const pb = pa + 4 * 64 * 4;
+  const float* const pc = pb + 4 * 64 * 4;
+  const float* const pd = pc + 4 * 64 * 4;
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %4, %17, off sc1\n\tglobal_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %8, %18, off sc1\n\tglobal_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\tglobal_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %12, %19, off sc1\n\tglobal_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\tglobal_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.v[0]), "=&v"(a.v[1]), "=&v"(a.v[2]), "=&v"(a.v[3]), "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]),
+        "=&v"(c.v[0]), "=&v"(c.v[1]), "=&v"(c.v[2]), "=&v"(c.v[3]), "=&v"(d.v[0]), "=&v"(d.v[1]), "=&v"(d.v[2]), "=&v"(d.v[3])
+      : "v"(pa), "v"(pb), "v"(pc), "v"(pd)
+      : "memory");
+}
+
 // LayerNorm over the N = 32 * NT channels a lane pair (l, l^32) holds in acc[NT] (registers 4g..4g+3 of tile t =
 // channels 32t + 8g + 4hf + 0..3)
 template <int NT>
@@ -276,14 +317,21 @@ struct FfnArgs {
   long long ldmid, sMid;
   int NI2;
   float eps_out2;
+  // SPLIT (round 5): a 128-row block's hidden extent cut once, the two pieces on different workgroups (sp_p blocks -> sp_p + 1
+  // workgroups, cut positions sp_k*), partial sums through ws[nblk][2][rows][C], the block's last arriver (cnt, self-resetting)
+  // adds them and runs the epilogue -- see ffn_split_plan
+  float* ws;
+  int* cnt;
+  int sp_p, sp_k0, sp_k1, nblk;  // sp_p = 1 or 2
 };
 
 // SINGLE (the arithmetic mode, FfnArgs.single at the launch) is a COMPILE-TIME parameter: as a run-time flag it put one uniform
 // branch in front of every step's two lo-term MFMAs (and around every hi / lo split), and the basic-block boundaries kept the
 // scheduler from overlapping a step's loads, DMA and split with its MFMAs: 192 -> 175 us at 24100 rows, 90 -> 79 us for the
 // C = 192 instantiation, the config-2 clip 6.87 -> 6.63 ms (A/B in one call, profiles/r04_single_template.txt).
-template <int C, int WAVES, int ACT, bool SINGLE, int ACT2 = 0>
+template <int C, int WAVES, int ACT, bool SINGLE, int ACT2 = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const FfnArgs p) {
+  static_assert(!(SPLIT && ACT2 != 0), "a chain is not split");
   constexpr int KS = C / 16, NT = C / 32;
   constexpr int SLOTS = (1 + 2 * KS + 4 * NT + WAVES - 1) / WAVES;
   constexpr int P = SLOTS * WAVES;  // pieces per stage, padded so that every wave issues exactly SLOTS DMAs (no branches)
@@ -292,7 +340,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   static_assert(SLOTS <= STEPS, "more DMA slots than loop steps");
   static_assert(2 * STAGE + WAVES * WT_BYTES <= 160 * 1024, "ring + staging tiles do not fit the LDS");
   // the ONLY LDS object (base offset 0): two ring stages, then one staging tile per wave
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + WAVES * WT_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + WAVES * WT_BYTES + (SPLIT ? 16 : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,11 +359,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   // simply advances by WAVES pieces per DMA for the whole kernel (the stream ends with one block of padding, so the
   // last iteration's prefetch reads defined bytes that are never consumed)
   const unsigned char* wp = p.wpk + (long long)(blockIdx.y / p.wdiv) * p.sW + (long long)wave * PIECE;
+  const unsigned char* const wp0 = wp;
   const unsigned voff = lane * 16;
   const unsigned wbase = wave * PIECE;
   auto dma = [&](int stage, int q) {
     const unsigned char* src = wp;
-    if constexpr (ACT2 != 0) {
+    if constexpr (ACT2 != 0 || SPLIT) {
       // the chain switches `wp` to the second stream inside run-time loops: tell the compiler it is still wave-uniform (the DMA's
       // base is an SGPR pair)
       const unsigned long long u = (unsigned long long)wp;
@@ -328,16 +377,40 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
     glds16(src, voff, wbase + (unsigned)(stage * STAGE + q * WAVES * PIECE));
     wp += WAVES * PIECE;
   };
-#pragma unroll
-  for (int q = 0; q < SLOTS; ++q) dma(0, q);
-
-  // ---- x: 32 tokens x C -> fp16 hi/lo B fragments, full-line loads staged through this wave's private tile
-  const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
   const float* const xb = p.x + blockIdx.y * p.sX;
   const float* const resb = p.res ? p.res + blockIdx.y * p.sRes : xb;
   const long long ldres = p.res ? p.ldres : p.ldx;
   float* const outb = p.out + blockIdx.y * p.sOut;
   float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
+  tce_amax_t amax = 0;
+  constexpr int single = SINGLE;
+  // SPLIT: workgroup i of a group of sp_p + 1 runs the head [0, k_i) of the group's block i, then the tail [k_(i-1), NC) of block
+  // i - 1 (a piece over chunks [c0, c1) is the stream's iterations c0 .. c1: the first applies W2[c0 - 1] to a zero H, the last
+  // computes an H nobody reads)
+  constexpr int NPC = SPLIT ? 2 : 1;
+  for (int pc = 0; pc < NPC; ++pc) {
+  int blk = blockIdx.x, nit = p.NI;
+  if constexpr (SPLIT) {
+    const int q = p.sp_p + 1, g = blockIdx.x / q, i = blockIdx.x - g * q;
+    int c0 = 0;
+    if (pc == 0) {
+      if (i == p.sp_p) continue;
+      blk = g * p.sp_p + i;
+      nit = (i == 0 ? p.sp_k0 : p.sp_k1) + 1;
+    } else {
+      if (i == 0) continue;
+      blk = g * p.sp_p + i - 1;
+      c0 = i == 1 ? p.sp_k0 : p.sp_k1;
+      nit = p.NI - c0;
+    }
+    if (blk >= p.nblk) continue;
+    wp = wp0 + (long long)c0 * (P * PIECE);
+  }
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) dma(0, q);
+
+  // ---- x: 32 tokens x C -> fp16 hi/lo B fragments, full-line loads staged through this wave's private tile
+  const int m0 = blk * (32 * WAVES) + wave * 32;
   h16x8 xh[KS], xl[KS];
   load_x_frags<C, (ACT >= 3)>(xb, p.ldx, p.a2, p.lda2, p.a2_rows, m0, p.M, wt, lane, p.g_in, p.be_in, p.eps_in, xh, xl, SINGLE);
 
@@ -346,8 +419,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
-  tce_amax_t amax = 0;
-  constexpr int single = SINGLE;
   h16x8 hh0, hl0, hh1, hl1;  // H^T of the previous chunk as B fragments (k-steps 0 and 1)
 #pragma unroll
   for (int j = 0; j < 8; ++j) hh0[j] = hl0[j] = hh1[j] = hl1[j] = (_Float16)0.f;
@@ -482,11 +553,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   using act1_t = std::integral_constant<int, ACT>;
   if constexpr (ACT2 == 0) {
     int it = 0;
-    for (; it + 1 < p.NI; it += 2) {
+    for (; it + 1 < nit; it += 2) {
       body(std::integral_constant<int, 0>{}, act1_t{});
       body(std::integral_constant<int, 1>{}, act1_t{});
     }
-    if (it < p.NI) body(std::integral_constant<int, 0>{}, act1_t{});
+    if (it < nit) body(std::integral_constant<int, 0>{}, act1_t{});
   } else {
     // ---- chain: stage 1, its epilogue into `mid` and into the operand registers, stage 2.  The ring parity is a run-time value
     // here (one uniform branch per iteration of 96 MFMAs).
@@ -542,6 +613,39 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   }
   if (stamps) stamps[2] = (long long)__builtin_amdgcn_s_memtime();
 
+  if constexpr (SPLIT) {
+    // this piece's partial sums -> ws[blk][role]; the block's second arriver adds the other piece's (a + b: the same bits
+    // whichever piece arrives last) and goes on to the epilogue, the first arriver is done with the block
+    const int role = pc;
+    const long long bi = (long long)blockIdx.y * p.nblk + blk;
+    float* const mine = p.ws + (bi * 2 + role) * (32 * WAVES * C);
+    const float* const other = p.ws + (bi * 2 + (role ^ 1)) * (32 * WAVES * C);
+    float* const mine_w = mine + wave * (32 * C);
+    const float* const other_w = other + wave * (32 * C);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) partial_store(oacc[t], mine_w, t, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through: visible to the partner before the counter moves
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(smem + 2 * STAGE + WAVES * WT_BYTES);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.cnt + bi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = __builtin_amdgcn_readfirstlane(*flag);
+    __syncthreads();  // (the flag word is rewritten by the next piece)
+    if (arrived == 0) continue;
+    if (tid == 0) __hip_atomic_store(p.cnt + bi, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    static_assert(NT % 4 == 0, "the split kernel exchanges four tiles at a time");
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 4) {
+      PartTile ot[4];
+      partial_load4(other_w, t0, lane, ot[0], ot[1], ot[2], ot[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) oacc[t0 + t][4 * g + c] += ot[t].v[g][c];
+    }
+  }
   // ---- epilogue: + b2 + residual, optional LayerNorm, stores -- all global traffic in full lines through the wave's
   // staging tile
   if constexpr (ACT2 != 0) {  // stage 2 of a chain: residual = this lane's own rows of `mid`, additive; stage 2's bias / LayerNorm
@@ -567,6 +671,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) tile_store(oacc[t], outb, p.ldo, m0, p.M, 32 * t, wt, lane, amax);
+  }  // pieces
   tce_range_report(p.range_flag, amax);
   if (stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -909,8 +1014,60 @@ inline int ffn_pieces(int C) {
 }
 inline long long ffn_units(int C, int Hd) { return (long long)(Hd / 32 + 2) * ffn_pieces(C) * 64; }  // + 1 block of padding
 
+// Hidden-extent split of the fused FFN (round 5).  A workgroup owns 128 rows and walks the whole hidden extent: 24100 rows are 189
+// workgroups -- 0.74 rounds of the chip's 256 CUs, and a round costs the same whether it is full or not.  With `p` blocks cut once
+// each and handed to p + 1 workgroups (head of block i, tail of block i - 1) a round is shorter by ~p / (p + 1): the plan that
+// minimises rounds x (iterations of the busiest workgroup + prologue / epilogue cost, in iterations) wins, and must win by 25 % ON
+// THAT MODEL: the kernel's throughput is nearly flat in the number of busy CUs (141 / 189 / 563 workgroups: 1.02 / 1.12 / 1.22
+// workgroups per us -- the power-bound finding of DESIGN 3.2), so the measured gains are a fraction of the model's: 18000 rows
+// (2 -> 3) 138 -> 121 us, 40800 rows (2 -> 3) 288 -> 251 us and config 3's clip 9.82 -> 9.60 ms, but 24100 rows (3 -> 4) only
+// 169 -> 163 us and config 2's clip 6.08 -> 6.23 ms with it (the 67 CUs the un-split launch leaves idle are where the clip's
+// parallel branches run).  Hence the margin: the 2 -> 3 and 1 -> 2 plans pass it, 3 -> 4 does not.
+struct FfnSplitPlan {
+  int p = 0, k[2] = {0, 0}, nblk = 0;
+  long long ws_floats = 0;
+};
+inline FfnSplitPlan ffn_split_plan(int M, int C, int Hd, int batch) {
+  FfnSplitPlan best;
+  const int B = tce_cdiv(M, 32 * ffn_waves(C)), NC = Hd / 32, CUS = 256;
+  if (C != 256 || NC < 24 || batch < 1) return best;
+  const int OVP = 3, OVF = 4;  // per piece: x load + split + partial store; per finished block: partial read + epilogue
+  auto rounds = [&](long long wgs) { return (double)((wgs + CUS - 1) / CUS); };
+  double best_cost = 0.75 * rounds((long long)B * batch) * (NC + 1 + OVP + OVF);
+  for (int p = 1; p <= 2; ++p) {  // (3 -> 4 was built and measured: see above)
+    const int wd = p == 1 ? 0 : (p * NC - 2 * (1 + OVP)) / (p + 1), ws_ = p == 1 ? (NC + 1) / 2 : wd + 1 + OVP;
+    int k[2] = {ws_, 0};
+    bool ok = ws_ >= 1 && ws_ <= NC - 1;
+    for (int i = 1; i < p && ok; ++i) {
+      k[i] = wd - (NC - k[i - 1]);
+      ok = k[i] >= 1 && k[i] <= NC - 1;
+    }
+    if (!ok) continue;
+    const int busiest = ws_ > NC - k[p - 1] ? ws_ : NC - k[p - 1];
+    const double cost = rounds((long long)tce_cdiv(B, p) * (p + 1) * batch) * (busiest + 1 + OVP + OVF);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best.p = p;
+      for (int i = 0; i < 2; ++i) best.k[i] = k[i];
+    }
+  }
+  if (best.p) {
+    best.nblk = B;
+    best.ws_floats = (long long)batch * B * 2 * (32 * ffn_waves(C)) * C;
+  }
+  return best;
+}
+
 template <int C, int WAVES>
 void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
+  if constexpr (C == 256) {
+    if (a.sp_p > 0 && act == 1) {
+      const dim3 grid(tce_cdiv(a.nblk, a.sp_p) * (a.sp_p + 1), batch), block(64 * WAVES);
+      if (a.single) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, true, 0, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, false, 0, true>), grid, block, 0, s, a);
+      return;
+    }
+  }
   const dim3 grid(tce_cdiv(a.M, 32 * WAVES), batch), block(64 * WAVES);
   if (a.single) {
     if (act == 1) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, true>), grid, block, 0, s, a);
@@ -1516,6 +1673,48 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   else if (C == 128) ffn_launch<128, 8>(a, act, s);
   else ffn_launch<96, 8>(a, act, s);
   TCE_CHECK_LAUNCH("tce_ffn_fused_f32");
+  return TCE_OK;
+}
+
+extern "C" int64_t tce_ffn_split_ws_floats(int32_t M, int32_t C, int32_t Hd, int32_t act) {
+  if (M <= 0 || !ffn_shape_ok(C, Hd) || act != 1) return 0;
+  return ffn_split_plan(M, C, Hd, 1).ws_floats;
+}
+
+extern "C" int32_t tce_ffn_split_counters(int32_t M, int32_t C, int32_t Hd, int32_t act) {
+  if (M <= 0 || !ffn_shape_ok(C, Hd) || act != 1) return 0;
+  return ffn_split_plan(M, C, Hd, 1).nblk;
+}
+
+extern "C" int tce_ffn_fused_split_f32(const float* x, int64_t ldx, const void* packed, const float* b2, const float* g_in,
+                                       const float* be_in, float eps_in, const float* g_out, const float* be_out, float eps_out,
+                                       float* out, int64_t ldo, int32_t M, int32_t C, int32_t Hd, int32_t act, float* ws,
+                                       int64_t ws_floats, int32_t* counters, int32_t n_counters, tceStream stream) {
+  TCE_CHECK_ARG(ffn_shape_ok(C, Hd), "tce_ffn_fused_split_f32: unsupported shape C=%d hidden=%d", C, Hd);
+  TCE_CHECK_ARG(M > 0 && x && packed && b2 && out, "tce_ffn_fused_split_f32: null pointer or M <= 0");
+  TCE_CHECK_ARG(act == 1, "tce_ffn_fused_split_f32: act must be 1 (ReLU)");
+  TCE_CHECK_ARG(ldx >= C && ldo >= C && ldx % 4 == 0 && ldo % 4 == 0, "tce_ffn_fused_split_f32: bad row pitch");
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(packed) && tce_aligned16(b2),
+                "tce_ffn_fused_split_f32: x/out/packed/b2 must be 16-byte aligned");
+  TCE_CHECK_ARG((!g_in || (be_in && tce_aligned16(g_in) && tce_aligned16(be_in))) &&
+                    (!g_out || (be_out && tce_aligned16(g_out) && tce_aligned16(be_out))),
+                "tce_ffn_fused_split_f32: LayerNorm gamma/beta must come in pairs, 16-byte aligned");
+  const FfnSplitPlan plan = ffn_split_plan(M, C, Hd, 1);
+  TCE_CHECK_ARG(plan.p > 0, "tce_ffn_fused_split_f32: no split is planned for M=%d C=%d hidden=%d (tce_ffn_split_ws_floats is 0): "
+                "call tce_ffn_fused_f32", M, C, Hd);
+  TCE_CHECK_ARG(ws && tce_aligned16(ws) && ws_floats >= plan.ws_floats && counters && n_counters >= plan.nblk,
+                "tce_ffn_fused_split_f32: workspace of %lld floats and %d zeroed counters needed", plan.ws_floats, plan.nblk);
+  TCE_CHECK_ARG(!(ws <= out + (long long)(M - 1) * ldo + C - 1 && out <= ws + plan.ws_floats - 1) &&
+                    !(ws <= x + (long long)(M - 1) * ldx + C - 1 && x <= ws + plan.ws_floats - 1),
+                "tce_ffn_fused_split_f32: the workspace overlaps x / out");
+  FfnArgs a = {};
+  a.x = x; a.wpk = (const unsigned char*)packed; a.b2 = b2; a.res_mode = 1;
+  a.g_in = g_in; a.be_in = be_in; a.g_out = g_out; a.be_out = be_out;
+  a.out = out; a.ldx = ldx; a.ldo = ldo; a.M = M; a.NI = Hd / 32 + 1; a.eps_in = eps_in; a.eps_out = eps_out; a.range_flag = tce_range_flag(); a.single = tce_gemm_single_pass();
+  a.wdiv = 1;
+  a.ws = ws; a.cnt = counters; a.sp_p = plan.p; a.sp_k0 = plan.k[0]; a.sp_k1 = plan.k[1]; a.nblk = plan.nblk;
+  ffn_launch<256, 4>(a, act, (hipStream_t)stream);
+  TCE_CHECK_LAUNCH("tce_ffn_fused_split_f32");
   return TCE_OK;
 }
 

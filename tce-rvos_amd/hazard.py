@@ -232,6 +232,13 @@ def _ffn_fused(a):
     return rd, [strided(_p(out), Cn * F, (M, ldo * F))]
 
 
+def _ffn_fused_split(a):
+    rd, wr = _ffn_fused(a)
+    ws, ws_floats, cnt, ncnt = a[16:20]
+    # the workspace and the counters are written and read inside the launch
+    return rd, wr + [dense(_p(ws), ws_floats * F), dense(_p(cnt), ncnt * 4)]
+
+
 def _ffn_pack(a, batched):
     W1, b1, W2, packed, Cn, Hd = a[:6]
     b = a[6] if batched else 1
@@ -347,6 +354,7 @@ MODELS = {
     "tce_ffn_pack_f32": lambda a: _ffn_pack(a, False),
     "tce_ffn_pack_batched_f32": lambda a: _ffn_pack(a, True),
     "tce_ffn_fused_f32": _ffn_fused,
+    "tce_ffn_fused_split_f32": _ffn_fused_split,
     "tce_xattn_prepare_f32": lambda a: (
         [dense(_p(a[0]), a[9] * a[7] * 256 * F), dense(_p(a[1]), a[9] * a[7] * 256 * F), dense(_p(a[2]), 257 * 256 * F),
          dense(_p(a[3]), 256 * 256 * F)],
@@ -398,7 +406,7 @@ MODELS = {
 }
 # Entry points that launch nothing (queries, process switches, graph helpers, tuning aids): passed through.
 NOT_LAUNCHES = {"tce_abi_version", "tce_last_error", "tce_gemm_select_tile", "tce_gemm_select_tile_ex", "tce_set_gemm_mode", "tce_set_gemm_mode_thread",
-                "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes",
+                "tce_get_gemm_mode", "tce_set_range_flag", "tce_groupnorm_nsplit", "tce_mha_ws_bytes", "tce_ffn_packed_bytes", "tce_ffn_split_ws_floats", "tce_ffn_split_counters",
                 "tce_rowlin_packed_bytes", "tce_conv3x3_packed_bytes", "tce_swin_attn_packed_bytes", "tce_thin_linear_splits", "tce_graph_begin", "tce_graph_end", "tce_graph_launch",
                 "tce_graph_destroy", "tce_graph_group"} | set(_lib.DEBUG_SIGNATURES)
 

@@ -18,15 +18,30 @@ class Arena:
     sequence of requests every time, so addresses are stable across calls -- what hipGraph replay needs."""
 
     ALIGN = 256
+    FLAGS = 1 << 16
 
     def __init__(self, device, nbytes):
         self.device = torch.device(device)
         self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         self.off = 0
         self.peak = 0
+        self.flags = None
+        self.flag_off = 0
 
     def reset(self):
         self.off = 0
+        self.flag_off = 0
+
+    def alloc_flags(self, n):
+        """n int32 counters that are ZERO now and that every kernel using them leaves zero (tce_ffn_fused_split_f32): a region of
+        its own beside the bump buffer, handed out in request order like the buffer's bytes, never recycled inside a pass."""
+        if self.flags is None:
+            self.flags = torch.zeros(self.FLAGS, dtype=torch.int32, device=self.device)
+        if self.flag_off + n > self.FLAGS:
+            raise MemoryError("tce_rvos_amd arena: out of split counters")
+        v = self.flags[self.flag_off:self.flag_off + n]
+        self.flag_off += n
+        return v
 
     def mark(self):
         return self.off
@@ -911,8 +926,19 @@ def ffn_supported(Cn, Hd):
     return lib().tce_ffn_packed_bytes(int(Cn), int(Hd)) > 0
 
 
-def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_out=1e-5, out=None, M=None):
-    """out = LN_out?(x + W2 act(W1 LN_in?(x) + b1) + b2); x [M, C] (row pitch = x.stride(0)); ln_* = (gamma, beta)."""
+FFN_SPLIT = os.environ.get("TCE_FFN_SPLIT", "1") != "0"  # A/B: 0 = a row block's hidden extent is never cut
+
+
+def ffn_split_need(M, Cn, Hd, act):
+    """(workspace floats, counters) of the hidden-extent split planned for this launch shape, (0, 0) when none is."""
+    if not FFN_SPLIT:
+        return 0, 0
+    return int(lib().tce_ffn_split_ws_floats(M, Cn, Hd, act)), int(lib().tce_ffn_split_counters(M, Cn, Hd, act))
+
+
+def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_out=1e-5, out=None, M=None, split=None):
+    """out = LN_out?(x + W2 act(W1 LN_in?(x) + b1) + b2); x [M, C] (row pitch = x.stride(0)); ln_* = (gamma, beta).
+    split = (workspace, counters) sized by ffn_split_need: the launch with the hidden extent cut (tce_ffn_fused_split_f32)."""
     _chk(x, "x")
     Cn = x.shape[-1]
     if M is None:
@@ -924,6 +950,13 @@ def ffn_fused(x, packed, b2, Hd, act, ln_in=None, ln_out=None, eps_in=1e-5, eps_
     gi, bi = (ln_in[0].data_ptr(), ln_in[1].data_ptr()) if ln_in is not None else (None, None)
     go, bo = (ln_out[0].data_ptr(), ln_out[1].data_ptr()) if ln_out is not None else (None, None)
     def go_():
+        if split is not None:
+            ws, cnt = split
+            assert cnt.dtype == torch.int32 and ws.dtype == torch.float32
+            check(lib().tce_ffn_fused_split_f32(x.data_ptr(), ldx, packed.data_ptr(), b2.data_ptr(), gi, bi, eps_in, go, bo, eps_out,
+                                                out.data_ptr(), ldo, M, Cn, Hd, act, ws.data_ptr(), ws.numel(), cnt.data_ptr(),
+                                                cnt.numel(), _stream()), "tce_ffn_fused_split_f32")
+            return
         check(lib().tce_ffn_fused_f32(x.data_ptr(), ldx, packed.data_ptr(), b2.data_ptr(), gi, bi, eps_in, go, bo, eps_out,
                                       out.data_ptr(), ldo, M, Cn, Hd, act, _stream()), "tce_ffn_fused_f32")
     if GEMM_PROFILE is None:

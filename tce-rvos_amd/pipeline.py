@@ -271,8 +271,12 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         (csrc/chain.hip); small M (a workgroup walks the whole hidden extent alone): two GEMMs + LayerNorm."""
         pk = w.get(pre + "ffn:pk:" + ops.get_gemm_mode()) if fused_ok else None
         if pk is not None and M >= FFN_FUSED_MIN_ROWS:
+            nws, ncnt = ops.ffn_split_need(M, D, ff, ACT_RELU)
+            m1 = ar.mark()
             ops.ffn_fused(x, pk, w[pre + l2 + ".bias"], ff, ACT_RELU, M=M,
-                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None)
+                          ln_out=(w[norm + ".weight"], w[norm + ".bias"]) if norm else None,
+                          split=(ar.alloc(nws), ar.alloc_flags(ncnt)) if nws else None)
+            ar.release(m1)
             return
         A = ar.alloc
         m1 = ar.mark()

@@ -858,6 +858,69 @@ def test_ffn_fused(ops, M, C, Hd, act, ln):
     assert torch.equal(xd, out)
 
 
+@pytest.mark.parametrize("M,ln,plan", [(18000, "out", 2), (17999, "none", 2), (40800, "both", 2), (36800, "out", 2), (16000, "out", 1),
+                                       (4600, "out", 1), (24100, "out", 0), (72000, "out", 0), (192800, "out", 0), (85570, "out", 0)])
+def test_ffn_fused_split(ops, M, ln, plan):
+    """tce_ffn_fused_split_f32 (round 5): a row block's hidden extent cut once, the pieces on different workgroups, the block's
+    second arriver adds the partial sums and runs the epilogue.  Against the un-split launch (one more fp32 addition per element)
+    and torch fp64 on a slice of rows; deterministic (a + b whichever piece arrives last: two runs bit-identical), the counters
+    back at zero, shapes for which no split is planned (full rounds already / few rows) say so and the entry point refuses them;
+    in place, ragged last block, LayerNorm on either side."""
+    from tce_rvos_amd._lib import TceError, lib
+    C, Hd = 256, 2048
+    nws, ncnt = ops.ffn_split_need(M, C, Hd, ops.ACT_RELU)
+    g = torch.Generator().manual_seed(M)
+    w1 = torch.randn(Hd, C, generator=g) / math.sqrt(C)
+    b1 = torch.randn(Hd, generator=g) * 0.2
+    w2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd)
+    b2 = torch.randn(C, generator=g) * 0.2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gam2, bet2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    pk = ops.ffn_pack(dev(w1), dev(b1), dev(w2))
+    kw = dict(ln_in=(dev(gam), dev(bet)) if ln == "both" else None, ln_out=(dev(gam2), dev(bet2)) if ln != "none" else None)
+    if plan == 0:
+        assert (nws, ncnt) == (0, 0)
+        x = torch.zeros(M, C, device="cuda")
+        with pytest.raises(TceError):
+            ops.ffn_fused(x, pk, dev(b2), Hd, ops.ACT_RELU, split=(torch.zeros(1 << 20, device="cuda"), torch.zeros(4096, dtype=torch.int32, device="cuda")), **kw)
+        return
+    assert ncnt == (M + 127) // 128 and nws == ncnt * 2 * 128 * C
+    x = torch.randn(M, C, generator=g)
+    xd = dev(x)
+    base = torch.empty_like(xd)
+    ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU, out=base, **kw)
+    ws, cnt = torch.full((nws,), float("nan"), device="cuda"), torch.zeros(ncnt, dtype=torch.int32, device="cuda")
+    out = torch.empty_like(xd)
+    ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU, out=out, split=(ws, cnt), **kw)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().max()) == 0
+    assert not bool(torch.isnan(out).any())
+    scale = float(base.abs().max())
+    assert float((out - base).abs().max()) <= 4e-6 * scale
+    out2 = xd.clone()                                                        # second launch on the same counters, in place
+    ops.ffn_fused(out2, pk, dev(b2), Hd, ops.ACT_RELU, split=(ws, cnt), **kw)
+    assert torch.equal(out2, out) and int(cnt.abs().max()) == 0
+    # other rows through the SAME workspace: a partner's partial sums read from a stale cache line would be the previous launch's
+    x3 = dev(torch.flip(x, (0,)) * 0.7 + 0.1)
+    base3, out3 = torch.empty_like(x3), torch.empty_like(x3)
+    ops.ffn_fused(x3, pk, dev(b2), Hd, ops.ACT_RELU, out=base3, **kw)
+    for _ in range(3):
+        ops.ffn_fused(x3, pk, dev(b2), Hd, ops.ACT_RELU, out=out3, split=(ws, cnt), **kw)
+        ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU, out=out2, split=(ws, cnt), **kw)
+    assert float((out3 - base3).abs().max()) <= 4e-6 * float(base3.abs().max()) and torch.equal(out2, out)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 200), torch.arange(M - 200, M)])
+    xr = x[rows].double()
+    y = F.layer_norm(xr, (C,), gam.double(), bet.double(), 1e-5) if ln == "both" else xr
+    o = xr + F.linear(torch.relu(F.linear(y, w1.double(), b1.double())), w2.double(), b2.double())
+    r64 = F.layer_norm(o, (C,), gam2.double(), bet2.double(), 1e-5) if ln != "none" else o
+    e_split = (out[rows.cuda()].cpu().double() - r64).abs().max().item()
+    e_base = (base[rows.cuda()].cpu().double() - r64).abs().max().item()
+    assert e_split <= 2 * e_base + 1e-6, (e_split, e_base)
+    with pytest.raises(TceError):                                            # too small a workspace is refused
+        ops.ffn_fused(xd, pk, dev(b2), Hd, ops.ACT_RELU, out=out, split=(ws[:nws - 4], cnt), **kw)
+    ops.check_range()
+
+
 def test_ffn_fused_rejects_bad_arguments(ops):
     from tce_rvos_amd._lib import TceError
     with pytest.raises(ValueError):

@@ -5,7 +5,7 @@ import torch
 from tce_rvos_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--shapes", default="24100x256x2048:relu:out,72000x256x2048:relu:out,18000x256x2048:relu:out,"
+ap.add_argument("--shapes", default="24100x256x2048:relu:out,72000x256x2048:relu:out,18000x256x2048:relu:out,40800x256x2048:relu:out,4600x256x2048:relu:out,"
                                     "72000x96x384:gelu:in,18000x192x768:gelu:in")
 ap.add_argument("--iters", type=int, default=20)
 a = ap.parse_args()
@@ -73,5 +73,12 @@ for spec in a.shapes.split(","):
     t_f = timeit(lambda: ops.ffn_fused(x, pk, b2, Hd, act, ln_in=ln_in, ln_out=ln_out, out=out), a.iters)
     t_u = timeit(unfused, a.iters)
     fl = 4.0 * M * C * Hd
+    nws, ncnt = ops.ffn_split_need(M, C, Hd, act) if (act == 1 and ln_in is None) else (0, 0)
+    if nws:  # the hidden-extent split planned for this shape
+        ws, cnt = torch.empty(nws, device=dev), torch.zeros(ncnt, dtype=torch.int32, device=dev)
+        out_s = torch.empty_like(x)
+        t_s = timeit(lambda: ops.ffn_fused(x, pk, b2, Hd, act, ln_out=ln_out, out=out_s, split=(ws, cnt)), a.iters)
+        d = (out_s - out).abs().max().item()
+        print(f"{'':32s} split: {t_s:8.1f} us = {fl / t_s * 1e-6:6.1f} TFLOP/s alg   x{t_f / t_s:.2f} of the un-split launch   max|split - unsplit| {d:.2e}")
     print(f"{spec:32s} max|err| {err:.2e} (|out| max {scale:.1f})  fused {t_f:8.1f} us = {fl / t_f * 1e-6:6.1f} TFLOP/s alg"
           f"   unfused {t_u:8.1f} us   x{t_u / t_f:.2f}", flush=True)
