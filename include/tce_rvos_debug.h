@@ -16,7 +16,7 @@ int tce_debug_set_epilogue(int32_t lds_staged);
 int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
 /* tuning aid: 1 = tce_msda_fused_f32 uses its LDS-staged form for encoder-sized calls (A/B timing, bit-identity
  * tests); 0 = default (measured not faster than the L2-gather form) */
-int tce_debug_msda_set_lds(int32_t on);
+int tce_debug_msda_set_lds(int32_t on); /* 0 default (= 4); 1 LDS-staged; 2 one point at a time; 3 / 4: two / four points in flight */
 /* tuning aid: 1 (default) = Swin window attention on the fp32 matrix cores; 0 = the VALU kernel (A/B timing) */
 int tce_debug_window_attn_set_mfma(int32_t on);
 /* tuning aid: 1 (default) = tce_mha_f32 runs key sequences >= 256 on the fp16 matrix cores (3 x fp16 split) in GEMM

@@ -49,6 +49,22 @@ __device__ __forceinline__ float bilinear_gather(const float* __restrict__ vbase
   return val;
 }
 
+// acc += w * (c1 v1 + c2 v2 + c3 v3 + c4 v4) for a lane's four channels, as ONE fixed chain of fused multiply-adds: every 16-byte
+// form of the gather (one point at a time, several in flight, LDS-staged) gives the same bits (left to the compiler's contraction
+// the forms differed in the last place)
+__device__ __forceinline__ void corner_acc(f32x4& acc, const float w, const float c1, const float c2, const float c3, const float c4,
+                                           const f32x4& v1, const f32x4& v2, const f32x4& v3, const f32x4& v4) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = c1 * v1[c];
+    t = __builtin_fmaf(c2, v2[c], t);
+    t = __builtin_fmaf(c3, v3[c], t);
+    t = __builtin_fmaf(c4, v4[c], t);
+    acc[c] = __builtin_fmaf(w, t, acc[c]);
+  }
+}
+
 // Fused form, dword-per-lane (fallback of msda_fused_q4_kernel for operands that are not 16-byte aligned): raw projection
 // rows (offsets | logits) + reference points in, softmax and offset normalisation inside.
 __global__ void __launch_bounds__(256) msda_fused_kernel(const float* __restrict__ value, const float* __restrict__ loc_or_proj,
@@ -212,13 +228,129 @@ __global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restr
       if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
       if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
       const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] += w * (c1 * v1[c] + c2 * v2[c] + c3 * v3[c] + c4 * v4[c]);
+      corner_acc(acc, w, c1, c2, c3, c4, v1, v2, v3, v4);
     }
   }
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
 }
 
+// The 16-byte form with U sampling points IN FLIGHT (round 5).  The loop above walks the 16 points one after the other, every
+// corner load behind a branch: a wave pays 16 memory round trips in a row, and the call runs at half of what the CUs' vector L1
+// can deliver (1.54 M wave-loads of 1 KiB = 46 us at 64 B/clk per CU; measured 86 us).  Here a step computes the U points'
+// corner addresses first -- branch-free: an absent corner (outside the level / on padding / a sample outside the map) keeps a
+// clamped, valid address and gets the coefficient 0 -- issues the 4 U loads together and then accumulates in the SAME order with
+// the SAME expression: a dropped corner contributes 0 * (a finite value) where the loop above adds c * 0, so the results are equal
+// (up to the sign of a zero).  L = P = 4 (the model's shape; other shapes take the loop above).
+template <int U>
+__global__ void __launch_bounds__(256) msda_fused_q4u_kernel(const float* __restrict__ value, const float* __restrict__ proj,
+                                                             const float* __restrict__ ref, float* __restrict__ out, LevelInfo lv,
+                                                             int N, int S, int M, int Lq, int ref_dim, int ref_per_frame,
+                                                             long long total) {
+  constexpr int L = 4, P = 4, LP = L * P;
+  static_assert(P % U == 0, "a step stays inside one level");
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  // (frame, query, head) of this lane's item in 32-bit arithmetic (N * Lq * M < 2^31 is checked at the launch; the 64-bit
+  // divisions of the loop form above are some 150 VALU instructions per wave)
+  unsigned pair, m;
+  if (M == 8) {
+    pair = (blockIdx.x >> 3) * 32u + (threadIdx.x >> 3);  // n*Lq + q
+    m = blockIdx.x & 7u;
+  } else {
+    const unsigned it = blockIdx.x * 32u + (threadIdx.x >> 3);  // (n*Lq + q)*M + m
+    pair = it / (unsigned)M;
+    m = it - pair * (unsigned)M;
+  }
+  const bool active = pair < (unsigned)(total / M);
+  if (!active) pair = 0, m = 0;
+  const int n = (int)(pair / (unsigned)Lq), q = (int)(pair - (unsigned)n * (unsigned)Lq);
+  const long long item = (long long)pair * M + m;
+  float px[2] = {0.f, 0.f}, py[2] = {0.f, 0.f}, pw[2] = {-3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pj = sub + 8 * e;
+    if (active) {
+      const int l = pj / P;
+      const int ncol = M * LP * 3;
+      const float* row = proj + ((long long)n * Lq + q) * ncol;
+      const float ox = row[(m * LP + pj) * 2 + 0];
+      const float oy = row[(m * LP + pj) * 2 + 1];
+      pw[e] = row[M * LP * 2 + m * LP + pj];  // logit
+      const float* rp = ref + ((long long)(ref_per_frame ? n : 0) * Lq + q) * ref_dim;
+      if (ref_dim == 2) {
+        px[e] = rp[0] * lv.vrx[l] + ox / (float)lv.W[l];
+        py[e] = rp[1] * lv.vry[l] + oy / (float)lv.H[l];
+      } else {
+        px[e] = rp[0] * lv.vrx[l] + ox / (float)P * (rp[2] * lv.vrx[l]) * 0.5f;
+        py[e] = rp[1] * lv.vry[l] + oy / (float)P * (rp[3] * lv.vry[l]) * 0.5f;
+      }
+    }
+  }
+  float mx = fmaxf(pw[0], pw[1]);
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float e0 = active ? __expf(pw[0] - mx) : 0.f, e1 = active ? __expf(pw[1] - mx) : 0.f;
+  float sum = e0 + e1;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float w0 = e0 / sum, w1 = e1 / sum;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // Addresses: the tensor's base (uniform) + a 32-bit byte offset per lane (N * S * M * D * 4 < 2^32 and M a power of two are
+  // checked at the launch): no 64-bit arithmetic, no integer multiply other than two 24-bit ones per point (v_mul_lo_u32 is a
+  // quarter-rate instruction: the first version of this kernel spent a quarter of its VALU cycles in 117 of them)
+  const char* const vb = reinterpret_cast<const char*>(value);
+  const unsigned rs_bytes_log2 = 31u - (unsigned)__builtin_clz((unsigned)(M * D * 4));
+  const unsigned lane_off = (((unsigned)n * (unsigned)S) << rs_bytes_log2) + (unsigned)(m * D + sub * 4) * 4u;
+#pragma unroll
+  for (int j0 = 0; j0 < LP; j0 += U) {
+    const int l = j0 / P;  // compile-time
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const unsigned Hv = (unsigned)lv.hv[l], Wv = (unsigned)lv.wv[l];
+    const unsigned base_l = lane_off + ((unsigned)lv.start[l] << rs_bytes_log2);
+    f32x4 v[U][4];
+    float cw[U][4], ww[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u, src = gbase + (j & 7);
+      const float x = __shfl(j >= 8 ? px[1] : px[0], src, 64), y = __shfl(j >= 8 ? py[1] : py[0], src, 64);
+      ww[u] = __shfl(j >= 8 ? w1 : w0, src, 64);
+      const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+      const bool inside = active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const float lh = h_im - hf, lw = w_im - wf;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      // an `inside` sample has h_low in [-1, Hl - 1]; anything else takes (0, 0) for the addresses and zero coefficients
+      const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      // 0 <= c < valid extent as ONE unsigned compare (h_high, w_high are never negative)
+      const bool kh0 = inside && (unsigned)h_low < Hv, kh1 = inside && (unsigned)h_high < Hv;
+      const bool kw0 = (unsigned)w_low < Wv, kw1 = (unsigned)w_high < Wv;
+      cw[u][0] = (kh0 && kw0) ? hh * hw : 0.f;
+      cw[u][1] = (kh0 && kw1) ? hh * lw : 0.f;
+      cw[u][2] = (kh1 && kw0) ? lh * hw : 0.f;
+      cw[u][3] = (kh1 && kw1) ? lh * lw : 0.f;
+      const unsigned hl_c = (unsigned)max(h_low, 0), wl_c = (unsigned)max(w_low, 0);
+      const unsigned hh_c = (unsigned)min(h_high, Hl - 1), wh_c = (unsigned)min(w_high, Wl - 1);
+      const unsigned r0 = __umul24(hl_c, (unsigned)Wl), r1 = __umul24(hh_c, (unsigned)Wl);
+      v[u][0] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r0 + wl_c) << rs_bytes_log2) + base_l));
+      v[u][1] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r0 + wh_c) << rs_bytes_log2) + base_l));
+      v[u][2] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r1 + wl_c) << rs_bytes_log2) + base_l));
+      v[u][3] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r1 + wh_c) << rs_bytes_log2) + base_l));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) corner_acc(acc, ww[u], cw[u][0], cw[u][1], cw[u][2], cw[u][3], v[u][0], v[u][1], v[u][2], v[u][3]);
+  }
+  if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
+}
+
+// (Round 5 also built the form with the GEOMETRY computed once per point instead of once per lane -- counters, tools/runs/r7b.sh:
+// these kernels are bound by VALU issue, 1955 (loop) / 1242 (U in flight) VALU instructions per wave of 4 cycles each = 88 / 56 us
+// of the 86 / 78 us, and most of them are the bilinear arithmetic all 8 lanes of an item repeat.  Lane i did it for its own two
+// points and the point loop broadcast nine values -- 4 coefficients, the weight, 4 row offsets -- inside the 8-lane group.
+// Bit-identical, but SLOWER: 98.4 vs 77.3 us at config 2, 159 vs 122 at config 3, 348 vs 284 at config 5 -- nine ds_bpermute per
+// point cost more in the CU's one LDS pipe than the ~30 VALU instructions they save on four SIMDs.  Removed.)
 // LDS-staged form of the fused kernel for the encoder's self-attention (thousands of queries per frame): a workgroup owns
 // one (frame, head) and a chunk of its queries, and first copies the COARSE levels of that (frame, head) value slice into
 // LDS -- at config 2 levels 1..3 are 1220 rows x 128 B = 152.5 KiB of the 160 KiB -- so that three quarters of the
@@ -325,8 +457,7 @@ __global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __res
           if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
         }
         const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) acc[cc] += w * (c1 * v1[cc] + c2 * v2[cc] + c3 * v3[cc] + c4 * v4[cc]);
+        corner_acc(acc, w, c1, c2, c3, c4, v1, v2, v3, v4);
       }
     }
     if (active) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q) * M + m) * D + sub * 4) = acc;
@@ -430,8 +561,7 @@ __global__ void __launch_bounds__(256) msda_plain_q4_dev_kernel(const float* __r
       if (h_high <= Hl - 1 && w_low >= 0) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
       if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
       const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] += w * (c1 * v1[c] + c2 * v2[c] + c3 * v3[c] + c4 * v4[c]);
+      corner_acc(acc, w, c1, c2, c3, c4, v1, v2, v3, v4);
     }
   }
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
@@ -813,7 +943,8 @@ extern "C" int tce_ms_deform_attn_backward_f32(const float* value, const int64_t
 // Measured (tools/msda_bench.py, profiles/r02_msda_lds.txt): the LDS-staged form is bit-identical and NOT faster than the
 // L2-gather form (102 vs 98 us at config 2, 150 vs 151 at config 3, 396 vs 325 at config 5): the gather is bound by
 // the number of wave-instructions per sample (shuffles, address arithmetic, 4 x 16-byte loads, 16 FMAs), not by where
-// the rows come from.  It stays in the library, off by default (tce_debug_msda_set_lds(1) selects it).
+// the rows come from.  It stays in the library, off by default (tce_debug_msda_set_lds(1) selects it; 2 = the one-point-at-a-time
+// 16-byte loop, 3 = two points in flight, 0 / 4 = four (the default): A/B of round 5's forms).
 static int g_msda_lds = 0;
 extern "C" int tce_debug_msda_set_lds(int32_t on) {
   g_msda_lds = on;
@@ -862,7 +993,7 @@ extern "C" int tce_msda_fused_valid_f32(const float* value, const float* proj, c
   }
   TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
   const long long total = (long long)N * Lq * M;
-  if (M == 8 && Lq >= 2048 && g_msda_lds && !valid_hw && tce_aligned16(value) && tce_aligned16(out)) {
+  if (M == 8 && Lq >= 2048 && g_msda_lds == 1 && !valid_hw && tce_aligned16(value) && tce_aligned16(out)) {
     // LDS-staged form: the largest suffix of levels whose (frame, head) slice fits the LDS
     int first = L;
     while (first > 1 && (long long)(start - lv.start[first - 1]) * D * 4 <= MSDA_LDS_BYTES) --first;
@@ -887,6 +1018,14 @@ extern "C" int tce_msda_fused_valid_f32(const float* value, const float* proj, c
   }
   if (tce_aligned16(value) && tce_aligned16(out)) {  // 16-byte form: 32 items per workgroup
     const int nb = (M == 8) ? tce_cdiv((long long)N * Lq, 32) * 8 : tce_cdiv(total, 32);
+    if (L == 4 && P == 4 && g_msda_lds != 2 && (long long)N * S * M * D < (1ll << 30) && (M & (M - 1)) == 0 && S < (1 << 24) && total < (1ll << 31)) {  // U points in flight (2 = the one-by-one loop, for A/B)
+      if (g_msda_lds == 3) hipLaunchKernelGGL((msda_fused_q4u_kernel<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out, lv, N,
+                                              S, M, Lq, ref_dim, ref_per_frame, total);
+      else hipLaunchKernelGGL((msda_fused_q4u_kernel<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out, lv, N, S, M, Lq,
+                              ref_dim, ref_per_frame, total);
+      TCE_CHECK_LAUNCH("tce_msda_fused_f32(q4u)");
+      return TCE_OK;
+    }
     hipLaunchKernelGGL(msda_fused_q4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, value, proj, ref, out, lv, N, S, M,
                        Lq, L, P, ref_dim, ref_per_frame, total);
     TCE_CHECK_LAUNCH("tce_msda_fused_f32");

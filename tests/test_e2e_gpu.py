@@ -1090,7 +1090,11 @@ def test_clip_group_matches_one_clip_at_a_time(models, backbone, G, T, H, W, L):
             assert err <= tol, (g, k, err, tol)
             for r in runs[1:]:
                 assert torch.equal(r[g][k], got), (g, k, "replay != eager")
-        m_ref, m_got = solo[g]["pred_masks"] > 0, runs[0][g]["pred_masks"] > 0
+        # mask agreement over the pixels whose sign means something: a logit inside the tolerance band above may fall on either
+        # side of zero in either run (on this 96 x 128 clip a mask has ~120 pixels: one such flip would read as IoU 0.992)
+        pm = solo[g]["pred_masks"]
+        sure = pm.abs() > 2e-5 * float(pm.abs().max()) + 1e-6
+        m_ref, m_got = (pm > 0) & sure, (runs[0][g]["pred_masks"] > 0) & sure
         inter, union = (m_ref & m_got).sum().item(), (m_ref | m_got).sum().item()
         assert union == 0 or inter / union > 0.9999
 

@@ -1048,6 +1048,15 @@ def test_msda_fused_lds_staged_is_bit_identical(ops):
     finally:
         lib().tce_debug_msda_set_lds(0)
     assert torch.equal(a, b)
+    # round 5: the default form keeps four sampling points in flight (branch-free corner addresses, zero coefficients for absent
+    # corners); the one-point-at-a-time loop (2) and two in flight (3) give the same bits
+    for mode in (2, 3):
+        lib().tce_debug_msda_set_lds(mode)
+        try:
+            c = ops.msda_fused(dv, dp, dr, shapes, N, S, M, Lq, L, P, 2, False)
+        finally:
+            lib().tce_debug_msda_set_lds(0)
+        assert torch.equal(c, b), mode
     off = proj[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
     aw = torch.softmax(proj[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
     norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32)
