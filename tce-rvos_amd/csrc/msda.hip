@@ -234,6 +234,35 @@ __global__ void __launch_bounds__(256) msda_fused_q4_kernel(const float* __restr
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
 }
 
+// One sampling point's bilinear geometry, branch-free: the four corner coefficients (zero for a corner outside the level / on
+// padding, all zero for a sample outside the map) and the corners' row indices inside the level, clamped so that every address is
+// valid.  Same formulas as the loop forms; `0 <= c < valid extent` is ONE unsigned compare (h_high, w_high are never negative);
+// 24-bit multiplies (v_mul_lo_u32 is a quarter-rate instruction).
+__device__ __forceinline__ void point_geometry(const float x, const float y, const bool active, const int Hl, const int Wl,
+                                               const unsigned Hv, const unsigned Wv, float (&cw)[4], unsigned (&idx)[4]) {
+  const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+  const bool inside = active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const float lh = h_im - hf, lw = w_im - wf;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  // an `inside` sample has h_low in [-1, Hl - 1]; anything else takes (0, 0) for the addresses and zero coefficients
+  const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const bool kh0 = inside && (unsigned)h_low < Hv, kh1 = inside && (unsigned)h_high < Hv;
+  const bool kw0 = (unsigned)w_low < Wv, kw1 = (unsigned)w_high < Wv;
+  cw[0] = (kh0 && kw0) ? hh * hw : 0.f;
+  cw[1] = (kh0 && kw1) ? hh * lw : 0.f;
+  cw[2] = (kh1 && kw0) ? lh * hw : 0.f;
+  cw[3] = (kh1 && kw1) ? lh * lw : 0.f;
+  const unsigned hl_c = (unsigned)max(h_low, 0), wl_c = (unsigned)max(w_low, 0);
+  const unsigned hh_c = (unsigned)min(h_high, Hl - 1), wh_c = (unsigned)min(w_high, Wl - 1);
+  const unsigned r0 = __umul24(hl_c, (unsigned)Wl), r1 = __umul24(hh_c, (unsigned)Wl);
+  idx[0] = r0 + wl_c;
+  idx[1] = r0 + wh_c;
+  idx[2] = r1 + wl_c;
+  idx[3] = r1 + wh_c;
+}
+
 // The 16-byte form with U sampling points IN FLIGHT (round 5).  The loop above walks the 16 points one after the other, every
 // corner load behind a branch: a wave pays 16 memory round trips in a row, and the call runs at half of what the CUs' vector L1
 // can deliver (1.54 M wave-loads of 1 KiB = 46 us at 64 B/clk per CU; measured 86 us).  Here a step computes the U points'
@@ -316,28 +345,10 @@ __global__ void __launch_bounds__(256) msda_fused_q4u_kernel(const float* __rest
       const int j = j0 + u, src = gbase + (j & 7);
       const float x = __shfl(j >= 8 ? px[1] : px[0], src, 64), y = __shfl(j >= 8 ? py[1] : py[0], src, 64);
       ww[u] = __shfl(j >= 8 ? w1 : w0, src, 64);
-      const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
-      const bool inside = active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const float lh = h_im - hf, lw = w_im - wf;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      // an `inside` sample has h_low in [-1, Hl - 1]; anything else takes (0, 0) for the addresses and zero coefficients
-      const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
-      const int h_high = h_low + 1, w_high = w_low + 1;
-      // 0 <= c < valid extent as ONE unsigned compare (h_high, w_high are never negative)
-      const bool kh0 = inside && (unsigned)h_low < Hv, kh1 = inside && (unsigned)h_high < Hv;
-      const bool kw0 = (unsigned)w_low < Wv, kw1 = (unsigned)w_high < Wv;
-      cw[u][0] = (kh0 && kw0) ? hh * hw : 0.f;
-      cw[u][1] = (kh0 && kw1) ? hh * lw : 0.f;
-      cw[u][2] = (kh1 && kw0) ? lh * hw : 0.f;
-      cw[u][3] = (kh1 && kw1) ? lh * lw : 0.f;
-      const unsigned hl_c = (unsigned)max(h_low, 0), wl_c = (unsigned)max(w_low, 0);
-      const unsigned hh_c = (unsigned)min(h_high, Hl - 1), wh_c = (unsigned)min(w_high, Wl - 1);
-      const unsigned r0 = __umul24(hl_c, (unsigned)Wl), r1 = __umul24(hh_c, (unsigned)Wl);
-      v[u][0] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r0 + wl_c) << rs_bytes_log2) + base_l));
-      v[u][1] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r0 + wh_c) << rs_bytes_log2) + base_l));
-      v[u][2] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r1 + wl_c) << rs_bytes_log2) + base_l));
-      v[u][3] = *reinterpret_cast<const f32x4*>(vb + (size_t)(((r1 + wh_c) << rs_bytes_log2) + base_l));
+      unsigned idx[4];
+      point_geometry(x, y, active, Hl, Wl, Hv, Wv, cw[u], idx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(vb + (size_t)((idx[k] << rs_bytes_log2) + base_l));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) corner_acc(acc, ww[u], cw[u][0], cw[u][1], cw[u][2], cw[u][3], v[u][0], v[u][1], v[u][2], v[u][3]);
@@ -370,8 +381,6 @@ __global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __res
   const int m = blockIdx.x & 7;
   const int rest = blockIdx.x >> 3;
   const int n = rest / chunks, c = rest - n * chunks;
-  const long long row_stride = (long long)M * D;
-  const float* vn = value + ((long long)n * S) * row_stride + m * D + sub * 4;
   const int staged_row0 = lv.start[first_staged];
   // stage rows [staged_row0, staged_row0 + staged_rows): 8 threads per 128-byte row; every load of a thread is issued
   // before the first LDS store (a load -> store loop would pay one memory round trip per 16 KiB)
@@ -426,38 +435,48 @@ __global__ void __launch_bounds__(1024) msda_fused_lds_kernel(const float* __res
     for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float w0 = e0 / sum, w1 = e1 / sum;
 
+    // the gather in the pipelined, branch-free form of msda_fused_q4u_kernel (L = P = 4): two points in flight, a staged level's
+    // corner rows come from LDS (row index * 128 bytes + this lane's 16), the others from the XCD's L2
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < LP; ++j) {
-      const int src = gbase + (j & 7);
-      const bool hi = j >= 8;  // loop-uniform
-      const float x = __shfl(hi ? px[1] : px[0], src, 64), y = __shfl(hi ? py[1] : py[0], src, 64);
-      const float w = __shfl(hi ? w1 : w0, src, 64);
-      const int l = j / P;
+    constexpr int U = 2;
+    const char* const vb = reinterpret_cast<const char*>(value);
+    const unsigned lane_off = (((unsigned)n * (unsigned)S) << 10) + (unsigned)(m * D + sub * 4) * 4u;  // M = 8: 1 KiB per position
+    // (the level loop stays rolled: unrolled, the compiler hoists every step's loads and the 1024-thread workgroup's 128 registers
+    // per lane spill -- 518 of them in the first build)
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
       const int Hl = lv.H[l], Wl = lv.W[l];
-      const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
-      if (active && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        const int h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
-        const int Hv = lv.hv[l], Wv = lv.wv[l];  // rows / columns that are not padding (their value rows read as zero)
-        if (l >= first_staged) {  // loop-uniform: this level lives in LDS
-          const float* lbase = reinterpret_cast<const float*>(smem) + (lv.start[l] - staged_row0) * D + sub * 4;
-          if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_low) * D);
-          if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = *reinterpret_cast<const f32x4*>(lbase + (h_low * Wl + w_high) * D);
-          if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_low) * D);
-          if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(lbase + (h_high * Wl + w_high) * D);
-        } else {
-          const float* vbase = vn + (long long)lv.start[l] * row_stride;
-          if (h_low >= 0 && w_low >= 0 && h_low < Hv && w_low < Wv) v1 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_low) * row_stride);
-          if (h_low >= 0 && w_high < Wv && h_low < Hv) v2 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_low * Wl + w_high) * row_stride);
-          if (h_high < Hv && w_low >= 0 && w_low < Wv) v3 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_low) * row_stride);
-          if (h_high < Hv && w_high < Wv) v4 = *reinterpret_cast<const f32x4*>(vbase + ((long long)h_high * Wl + w_high) * row_stride);
+      const unsigned Hv = (unsigned)lv.hv[l], Wv = (unsigned)lv.wv[l];
+      const bool hi = l >= 2;  // points 8..15 are the lane's second triple
+      const float sx = hi ? px[1] : px[0], sy = hi ? py[1] : py[0], sw = hi ? w1 : w0;
+      const unsigned lbase = (unsigned)(lv.start[l] - staged_row0) * 128u + (unsigned)sub * 16u;
+      const unsigned gb = lane_off + ((unsigned)lv.start[l] << 10);
+      const bool in_lds = l >= first_staged;  // uniform
+#pragma unroll
+      for (int p0 = 0; p0 < 4; p0 += U) {
+        f32x4 v[U][4];
+        float cw[U][4], ww[U];
+        unsigned idx[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int src = gbase + 4 * (l & 1) + p0 + u;
+          const float x = __shfl(sx, src, 64), y = __shfl(sy, src, 64);
+          ww[u] = __shfl(sw, src, 64);
+          point_geometry(x, y, active, Hl, Wl, Hv, Wv, cw[u], idx[u]);
         }
-        const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
-        corner_acc(acc, w, c1, c2, c3, c4, v1, v2, v3, v4);
+        if (in_lds) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(smem + idx[u][k] * 128u + lbase);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(vb + (size_t)((idx[u][k] << 10) + gb));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) corner_acc(acc, ww[u], cw[u][0], cw[u][1], cw[u][2], cw[u][3], v[u][0], v[u][1], v[u][2], v[u][3]);
       }
     }
     if (active) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q) * M + m) * D + sub * 4) = acc;
@@ -993,7 +1012,7 @@ extern "C" int tce_msda_fused_valid_f32(const float* value, const float* proj, c
   }
   TCE_CHECK_ARG(start == S, "tce_msda_fused_f32: sum(H*W)=%d != S=%d", start, S);
   const long long total = (long long)N * Lq * M;
-  if (M == 8 && Lq >= 2048 && g_msda_lds == 1 && !valid_hw && tce_aligned16(value) && tce_aligned16(out)) {
+  if (M == 8 && Lq >= 2048 && g_msda_lds == 1 && !valid_hw && L == 4 && P == 4 && (long long)N * S * M * D < (1ll << 30) && tce_aligned16(value) && tce_aligned16(out)) {
     // LDS-staged form: the largest suffix of levels whose (frame, head) slice fits the LDS
     int first = L;
     while (first > 1 && (long long)(start - lv.start[first - 1]) * D * 4 <= MSDA_LDS_BYTES) --first;
