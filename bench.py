@@ -52,8 +52,9 @@ def _pmc_traffic(kernel_prefix):
             with open(os.path.join(ROOT, summary)) as f:
                 k = json.load(f)["kernels"]
             hits = [v for name, v in k.items() if name.startswith(kernel_prefix)]
-            if hits:
-                return round(hits[0]["hbm_bytes_per_launch"]), summary + " (rocprofv3 --pmc passes, not this run)"
+            if hits:  # several instantiations share a prefix: the one that moved the most bytes over the pass
+                hit = max(hits, key=lambda v: v["hbm_bytes_per_launch"] * v.get("launches", 1))
+                return round(hit["hbm_bytes_per_launch"]), summary + " (rocprofv3 --pmc passes, not this run)"
         except Exception:  # noqa: BLE001
             pass
     return None, None
@@ -360,22 +361,22 @@ def main():
                                        "share_of_mfma_time": round(tsec / sum(v[1] for v in agg.values()), 3)}
 
         # HBM side: the encoder's MSDA calls (the launches with the most query rows)
-        mprof = [h for h in hprof if h[0] == "msda_fused_q4_kernel"]
+        mprof = [h for h in hprof if h[0] == "msda_fused_q4u_kernel"]
         if mprof:
             rows_max = max(h[1] for h in mprof)
             enc = [h for h in mprof if h[1] == rows_max]
             hb = sum(h[2] for h in enc)
             hs = sum(h[3].elapsed_time(h[4]) for h in enc) * 1e-3
-            htraffic, hsrc = _pmc_traffic("msda_fused_q4_kernel")
-            roofline_hbm = {"bound": "hbm", "kernel": "msda_fused_q4_kernel (encoder self-attention call)",
+            htraffic, hsrc = _pmc_traffic("msda_fused_q4")
+            roofline_hbm = {"bound": "hbm", "kernel": "msda_fused_q4u_kernel<4> (encoder self-attention call)",
                             "achieved": round(hb / hs / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(hb / hs / 8e12, 4), "traffic": htraffic, "traffic_source": hsrc,
                             "launches_per_step": len(enc) // n_inst, "avg_launch_us": round(hs / len(enc) * 1e6, 2),
                             "bytes_per_launch": hb / len(enc),
-                            "note": "gathers 1.58 GB of bilinear corner rows per launch from the XCD L2s (not algorithmic bytes)"}
+                            "note": "gathers 1.58 GB of bilinear corner rows per launch through the CUs' vector L1s (not algorithmic bytes)"}
             # the other HBM-bound kernels that report their algorithmic bytes: largest launch of each kind
             others = {}
-            for name in sorted(set(h[0] for h in hprof) - {"msda_fused_q4_kernel"}):
+            for name in sorted(set(h[0] for h in hprof) - {"msda_fused_q4u_kernel"}):
                 rows_k = max(h[1] for h in hprof if h[0] == name)
                 sel = [h for h in hprof if h[0] == name and h[1] == rows_k]
                 kb = sum(h[2] for h in sel)

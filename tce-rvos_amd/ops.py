@@ -584,7 +584,7 @@ def msda_fused(value, proj, ref, shapes_hw, N, S, M, Lq, L, P, ref_dim, ref_per_
     go()
     e1.record()
     # algorithmic bytes: value read once + the 384-wide offsets|weights projection + the output rows
-    HBM_PROFILE.append(("msda_fused_q4_kernel", N * Lq, 4.0 * (N * S * M * 32 + N * Lq * M * L * P * 3 + N * Lq * M * 32), e0, e1))
+    HBM_PROFILE.append(("msda_fused_q4u_kernel", N * Lq, 4.0 * (N * S * M * 32 + N * Lq * M * L * P * 3 + N * Lq * M * 32), e0, e1))
     return out
 
 
