@@ -332,26 +332,35 @@ __global__ void __launch_bounds__(256) msda_fused_q4u_kernel(const float* __rest
   const char* const vb = reinterpret_cast<const char*>(value);
   const unsigned rs_bytes_log2 = 31u - (unsigned)__builtin_clz((unsigned)(M * D * 4));
   const unsigned lane_off = (((unsigned)n * (unsigned)S) << rs_bytes_log2) + (unsigned)(m * D + sub * 4) * 4u;
-#pragma unroll
-  for (int j0 = 0; j0 < LP; j0 += U) {
-    const int l = j0 / P;  // compile-time
+  // the level loop stays rolled (unrolled, the compiler hoists all sixteen points' shuffles and address arithmetic: 118 registers
+  // per lane instead of 83).  Occupancy is not what bounds the kernel: forced to 6 / 8 waves per SIMD it ran 74.7 / 82.2 us against
+  // 77.1 (tools/runs/r7c.sh); the texture addressers are busy 65-72 % of the launch (TA_BUSY, tools/runs/r7f.sh) -- 1.54 M wave-loads
+  // of 1 KiB at 64 B/clk per CU are 58 % of the launch on their own -- and VALU issue about as much.
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
     const int Hl = lv.H[l], Wl = lv.W[l];
     const unsigned Hv = (unsigned)lv.hv[l], Wv = (unsigned)lv.wv[l];
     const unsigned base_l = lane_off + ((unsigned)lv.start[l] << rs_bytes_log2);
-    f32x4 v[U][4];
-    float cw[U][4], ww[U];
+    const bool hi = l >= 2;  // points 8..15 are the lane's second pair
+    const float sx = hi ? px[1] : px[0], sy = hi ? py[1] : py[0], sw = hi ? w1 : w0;
+    const int src0 = gbase + 4 * (l & 1);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u, src = gbase + (j & 7);
-      const float x = __shfl(j >= 8 ? px[1] : px[0], src, 64), y = __shfl(j >= 8 ? py[1] : py[0], src, 64);
-      ww[u] = __shfl(j >= 8 ? w1 : w0, src, 64);
-      unsigned idx[4];
-      point_geometry(x, y, active, Hl, Wl, Hv, Wv, cw[u], idx);
+    for (int p0 = 0; p0 < P; p0 += U) {
+      f32x4 v[U][4];
+      float cw[U][4], ww[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(vb + (size_t)((idx[k] << rs_bytes_log2) + base_l));
+      for (int u = 0; u < U; ++u) {
+        const int src = src0 + p0 + u;
+        const float x = __shfl(sx, src, 64), y = __shfl(sy, src, 64);
+        ww[u] = __shfl(sw, src, 64);
+        unsigned idx[4];
+        point_geometry(x, y, active, Hl, Wl, Hv, Wv, cw[u], idx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(vb + (size_t)((idx[k] << rs_bytes_log2) + base_l));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) corner_acc(acc, ww[u], cw[u][0], cw[u][1], cw[u][2], cw[u][3], v[u][0], v[u][1], v[u][2], v[u][3]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) corner_acc(acc, ww[u], cw[u][0], cw[u][1], cw[u][2], cw[u][3], v[u][0], v[u][1], v[u][2], v[u][3]);
   }
   if (active) *reinterpret_cast<f32x4*>(out + item * D + sub * 4) = acc;
 }
