@@ -94,6 +94,14 @@ int tce_layernorm_f32(const float* x, const float* r, const float* gamma, const 
 int tce_groupnorm_nsplit(int32_t HW);
 int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
                       int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream);
+/* GroupNorm (+ ReLU) of the coarse map x[T, h, w, C] written through a nearest-neighbour up-sampling onto the finer map and added to it
+ * (round 5): out[t, yo, xo, :] = add[t, yo, xo, :] + act(GN(x))[t, yi, xi, :], yi = min(floor(yo * h / ho), h - 1) -- the pixel
+ * decoder's top-down merge `cur_fpn + F.interpolate(y, size=cur_fpn.shape[-2:], mode="nearest")` with y = ReLU(GN(conv))
+ * (segmentation.py:199-203) as the apply pass of the GroupNorm itself: the normalised coarse map is never written.  Same arithmetic
+ * as tce_groupnorm_f32 followed by tce_resize_nearest_f32.  out may alias add (not x); ws as for tce_groupnorm_f32 over h * w. */
+int tce_groupnorm_up_add_f32(const float* x, const float* gamma, const float* beta, const float* add, float* out, float* ws,
+                             int32_t T, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t C, int32_t G, float eps,
+                             int32_t relu, tceStream stream);
 
 /* ResNet-50 stem (row A11; models/backbone.py:92-96 builds torchvision's resnet50 with FrozenBatchNorm2d :46-56):
  * conv 7x7 stride 2 pad 3, 3 -> 64, + folded frozen BN + ReLU.  frames NCHW [T,3,H,W] -> channels-last

@@ -77,6 +77,7 @@ SIGNATURES = {
     "tce_layernorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, c_f]),
     "tce_groupnorm_nsplit": (i32, [i32]),
     "tce_groupnorm_f32": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, f32, i32, c_f]),
+    "tce_groupnorm_up_add_f32": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, i32, f32, i32, c_f]),
     "tce_resnet_stem_f32": (i32, [c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tce_maxpool3x3s2_cl_f32": (i32, [c_f, c_f, i32, i32, i32, i32, c_f]),
     "tce_resize_h_u8": (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, c_f]),

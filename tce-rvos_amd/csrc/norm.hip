@@ -419,21 +419,12 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, con
   }
   n = nt;
 }
-// Applies the normalisation.  The merge of the per-chunk partials ("finalize") is done HERE, by every workgroup for its
-// frame's G groups (16 lanes per group: a lane's partials are independent loads, then a 4-step butterfly of Chan's
-// formula): G * nsplit * 12 bytes from L2 per workgroup instead of a separate 5 us launch on the pixel decoder's critical
-// path (12 per clip).
-__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ ws,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ out,
-                                                              int HW, int C, int G, int relu, int rows_per_block,
-                                                              int nsplit, float eps) {
-  extern __shared__ float sm[];  // scale[C], shift[C]
+// scale[c] = rstd * gamma[c], shift[c] = beta[c] - mean * scale[c] of frame t into LDS; the merge of the per-chunk partials is done
+// here (see groupnorm_apply_kernel).  Ends with a workgroup barrier.
+__device__ __forceinline__ void groupnorm_scale_shift(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* scale, float* shift, const int t,
+                                                      const int C, const int G, const int nsplit, const float eps) {
   __shared__ float sMean[64], sRstd[64];
-  float* scale = sm;
-  float* shift = sm + C;
-  const int t = blockIdx.y;
   const int cg = C / G;
   {
     const int l16 = threadIdx.x & 15;
@@ -473,6 +464,23 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __res
     shift[c] = beta[c] - mean * sc;
   }
   __syncthreads();
+}
+
+// Applies the normalisation.  The merge of the per-chunk partials ("finalize") is done HERE, by every workgroup for its
+// frame's G groups (16 lanes per group: a lane's partials are independent loads, then a 4-step butterfly of Chan's
+// formula): G * nsplit * 12 bytes from L2 per workgroup instead of a separate 5 us launch on the pixel decoder's critical
+// path (12 per clip).
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ ws,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ out,
+                                                              int HW, int C, int G, int relu, int rows_per_block,
+                                                              int nsplit, float eps) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  float* scale = sm;
+  float* shift = sm + C;
+  const int t = blockIdx.y;
+  groupnorm_scale_shift(ws, gamma, beta, scale, shift, t, C, G, nsplit, eps);
   const int c4 = C >> 2;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min((long long)HW, r0 + rows_per_block);
@@ -492,6 +500,48 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __res
     o4[i] = o;
   }
 }
+
+// The same, written through a nearest-neighbour up-sampling onto a finer map and added to it (round 5):
+//     out[t, yo, xo, :] = add[t, yo, xo, :] + act(GN(x)[t, yi, xi, :]),   yi = min(floor(yo * h / ho), h - 1) (F.interpolate "nearest")
+// -- the pixel decoder's top-down merge `cur_fpn + interpolate(y)` with y = ReLU(GN(conv)) (segmentation.py:199-203): the
+// normalised coarse map is never written, and the merge is not a launch of its own.  Same arithmetic as the two launches
+// (normalise, ReLU, then + add).  out may alias add.
+__global__ void __launch_bounds__(256) groupnorm_apply_up_kernel(const float* __restrict__ x, const float* __restrict__ ws,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* add, float* out, int h, int w, int ho, int wo,
+                                                                 int C, int G, int relu, int rows_per_block, int nsplit, float eps) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  float* scale = sm;
+  float* shift = sm + C;
+  const int t = blockIdx.y;
+  groupnorm_scale_shift(ws, gamma, beta, scale, shift, t, C, G, nsplit, eps);
+  const int c4 = C >> 2;
+  const long long HWo = (long long)ho * wo;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(HWo, r0 + rows_per_block);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (long long)t * h * w * C);
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(add + (long long)t * HWo * C);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + (long long)t * HWo * C);
+  const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
+  const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
+  const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+  for (long long i = r0 * c4 + threadIdx.x; i < r1 * c4; i += 256) {
+    const int c = (int)(i % c4);
+    const int ro = (int)(i / c4);
+    const int yo = ro / wo, xo = ro - yo * wo;
+    const int yi = min((int)floorf((float)yo * sy), h - 1), xi = min((int)floorf((float)xo * sx), w - 1);
+    const f32x4 v = x4[((long long)yi * w + xi) * c4 + c], a = sc4[c], b = sh4[c];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = v[j] * a[j] + b[j];
+      if (relu) o[j] = fmaxf(o[j], 0.f);
+    }
+    o += a4[i];
+    o4[i] = o;
+  }
+}
+
 
 }  // namespace
 
@@ -562,6 +612,38 @@ extern "C" int tce_patch_embed_f32(const float* frames, const float* w, const fl
 
 static int groupnorm_rows_per(int HW) { return HW >= 4096 ? 128 : (HW >= 512 ? 32 : 8); }
 extern "C" int tce_groupnorm_nsplit(int32_t HW) { return tce_cdiv(HW, groupnorm_rows_per(HW)); }
+
+static void groupnorm_stats_launch(const float* x, float* ws, int T, int HW, int C, int G, hipStream_t s);
+
+extern "C" int tce_groupnorm_up_add_f32(const float* x, const float* gamma, const float* beta, const float* add, float* out,
+                                        float* ws, int32_t T, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t C, int32_t G,
+                                        float eps, int32_t relu, tceStream stream) {
+  TCE_CHECK_ARG(x && gamma && beta && add && out && ws, "tce_groupnorm_up_add_f32: null pointer");
+  TCE_CHECK_ARG(T > 0 && h > 0 && w > 0 && ho > 0 && wo > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && C % 4 == 0,
+                "tce_groupnorm_up_add_f32: bad shape (G <= 64)");
+  TCE_CHECK_ARG(tce_aligned16(x) && tce_aligned16(out) && tce_aligned16(add), "tce_groupnorm_up_add_f32: x/add/out must be 16-byte aligned");
+  TCE_CHECK_ARG(x != out, "tce_groupnorm_up_add_f32: out may alias add, not x");
+  const int HW = h * w, nsplit = tce_cdiv(HW, groupnorm_rows_per(HW));
+  hipStream_t s = (hipStream_t)stream;
+  groupnorm_stats_launch(x, ws, T, HW, C, G, s);
+  const int rows_per_block = 64;
+  hipLaunchKernelGGL(groupnorm_apply_up_kernel, dim3(tce_cdiv(ho * wo, rows_per_block), T), dim3(256), (size_t)2 * C * sizeof(float), s,
+                     x, ws, gamma, beta, add, out, h, w, ho, wo, C, G, relu, rows_per_block, nsplit, eps);
+  TCE_CHECK_LAUNCH("tce_groupnorm_up_add_f32");
+  return TCE_OK;
+}
+
+static void groupnorm_stats_launch(const float* x, float* ws, int T, int HW, int C, int G, hipStream_t s) {
+  const int rows_per = groupnorm_rows_per(HW), nsplit = tce_cdiv(HW, rows_per);
+  if (C == 256 && (G == 8 || G == 16 || G == 32 || G == 64)) {
+    const dim3 grid(nsplit, T);
+    if (rows_per == 128) hipLaunchKernelGGL(groupnorm_stats_rows_kernel<32>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+    else if (rows_per == 32) hipLaunchKernelGGL(groupnorm_stats_rows_kernel<8>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+    else hipLaunchKernelGGL(groupnorm_stats_rows_kernel<2>, grid, dim3(256), 0, s, x, ws, HW, G, rows_per, nsplit);
+  } else {
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(T * G, nsplit), dim3(256), 0, s, x, ws, HW, C, G, nsplit);
+  }
+}
 
 extern "C" int tce_groupnorm_f32(const float* x, const float* gamma, const float* beta, float* out, float* ws, int32_t T,
                                  int32_t HW, int32_t C, int32_t G, float eps, int32_t relu, tceStream stream) {

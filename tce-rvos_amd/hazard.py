@@ -257,6 +257,14 @@ def _groupnorm(a):
             [dense(_p(out), T * HW * Cn * F), w])
 
 
+def _groupnorm_up_add(a):
+    x, gamma, beta, add, out, ws, T, h, w_, ho, wo, Cn, G = a[:13]
+    nsplit = _lib.lib_raw().tce_groupnorm_nsplit(h * w_)
+    w = dense(_p(ws), T * G * (nsplit * 3 + 2) * F)
+    return ([dense(_p(x), T * h * w_ * Cn * F), dense(_p(gamma), Cn * F), dense(_p(beta), Cn * F), dense(_p(add), T * ho * wo * Cn * F), w],
+            [dense(_p(out), T * ho * wo * Cn * F), w])
+
+
 def _mask_pack(a):
     params, w0f, tail, nl, T, Q, Cm = a[:7]
     npar = 8 * (Cm + 2) + 64 + 8 + 8 + 8 + 1
@@ -302,6 +310,7 @@ MODELS = {
     "tce_layernorm_f32": lambda a: ([dense(_p(a[0]), a[5] * a[6] * F), dense(_p(a[1]), a[5] * a[6] * F), dense(_p(a[2]), a[6] * F),
                                      dense(_p(a[3]), a[6] * F)], [dense(_p(a[4]), a[5] * a[6] * F)]),
     "tce_groupnorm_f32": _groupnorm,
+    "tce_groupnorm_up_add_f32": _groupnorm_up_add,
     "tce_resnet_stem_f32": lambda a: ([dense(_p(a[0]), a[4] * 3 * a[5] * a[6] * F), dense(_p(a[1]), 147 * 64 * F), dense(_p(a[2]), 64 * F)],
                                       [dense(_p(a[3]), a[4] * ((a[5] - 1) // 2 + 1) * ((a[6] - 1) // 2 + 1) * 64 * F)]),
     "tce_maxpool3x3s2_cl_f32": lambda a: ([dense(_p(a[0]), a[2] * a[3] * a[4] * a[5] * F)],

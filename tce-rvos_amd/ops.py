@@ -18,14 +18,16 @@ class Arena:
     sequence of requests every time, so addresses are stable across calls -- what hipGraph replay needs."""
 
     ALIGN = 256
-    FLAGS = 1 << 16
+    FLAGS = 1 << 14
 
     def __init__(self, device, nbytes):
         self.device = torch.device(device)
         self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         self.off = 0
         self.peak = 0
-        self.flags = None
+        # zeroed now, outside any graph capture (an allocation inside a capture would come from the capture's private pool and its
+        # fill would become a graph node)
+        self.flags = torch.zeros(self.FLAGS, dtype=torch.int32, device=self.device)
         self.flag_off = 0
 
     def reset(self):
@@ -35,8 +37,6 @@ class Arena:
     def alloc_flags(self, n):
         """n int32 counters that are ZERO now and that every kernel using them leaves zero (tce_ffn_fused_split_f32): a region of
         its own beside the bump buffer, handed out in request order like the buffer's bytes, never recycled inside a pass."""
-        if self.flags is None:
-            self.flags = torch.zeros(self.FLAGS, dtype=torch.int32, device=self.device)
         if self.flag_off + n > self.FLAGS:
             raise MemoryError("tce_rvos_amd arena: out of split counters")
         v = self.flags[self.flag_off:self.flag_off + n]
@@ -349,6 +349,20 @@ def groupnorm_cl(x, gamma, beta, T, HW, Cn, G, eps=1e-5, relu=False, out=None, w
     _hbm_timed("groupnorm (stats + apply)", T * HW, 3.0 * T * HW * Cn * 4, lambda: check(
         lib().tce_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), T, HW, Cn, G, eps,
                                 1 if relu else 0, _stream()), "tce_groupnorm_f32"))
+    return out
+
+
+GN_UP_FUSE = os.environ.get("TCE_GN_UP_FUSE", "1") != "0"  # A/B: 0 = GroupNorm apply and the top-down merge as two launches
+
+
+def groupnorm_up_add(x, gamma, beta, T, h, w, ho, wo, Cn, G, add, out, eps=1e-5, relu=True, ws=None, alloc=None):
+    """out <- add + act(GN(x)) up-sampled (nearest) from [T, h, w, C] onto [T, ho, wo, C] (tce_groupnorm_up_add_f32)."""
+    _chk(x, "x")
+    nsplit = lib().tce_groupnorm_nsplit(h * w)
+    if ws is None:
+        ws = alloc(T * G * (nsplit * 3 + 2)) if alloc else torch.empty(T * G * (nsplit * 3 + 2), dtype=torch.float32, device=x.device)
+    check(lib().tce_groupnorm_up_add_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), add.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                         T, h, w, ho, wo, Cn, G, eps, 1 if relu else 0, _stream()), "tce_groupnorm_up_add_f32")
     return out
 
 

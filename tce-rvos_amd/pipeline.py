@@ -1083,11 +1083,26 @@ def _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=
     sizes = sc["sizes"]
     pd = "pixel_decoder."
 
+    pending = {}  # id of a y buffer that holds the RAW convolution output of its stage -> that stage (its GroupNorm is still due)
+
     def merge_conv(tgt, stage, y, y_hw, arx, y_new):
-        """top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU -> y_new"""
+        """top-down merge (nearest up-sampling to the exact finer size) + 3x3 conv + GN(8) + ReLU -> y_new.  The GroupNorm + ReLU
+        of a stage whose output only feeds the next merge (stages 4..2) is not applied here: y_new then holds the raw convolution
+        output and the NEXT merge applies it while it up-samples and adds (ops.groupnorm_up_add: one apply pass instead of an
+        apply pass and a merge pass).  Stage 1's output feeds the mask_features convolution: normalised here."""
         h, ww = sizes[stage - 1]
         if y is not None:
-            ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
+            prev = pending.pop(id(y), None)
+            if prev is not None:
+                ops.groupnorm_up_add(y, w[f"{pd}layer_{prev}.norm.weight"], w[f"{pd}layer_{prev}.norm.bias"], T, y_hw[0], y_hw[1], h, ww,
+                                     D, 8, add=tgt, out=tgt, relu=True, alloc=arx.alloc)
+            else:
+                ops.resize_nearest(y, T, y_hw[0], y_hw[1], h, ww, D, add=tgt, out=tgt)
+        if ops.GN_UP_FUSE and stage > 1:
+            with model.arith("pixel.conv"):
+                ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, out=y_new, alloc=arx.alloc)
+            pending[id(y_new)] = stage
+            return
         with model.arith("pixel.conv"):
             conv, _, _ = ops.conv2d_cl(tgt, w[f"{pd}layer_{stage}.weight:cl"], T, h, ww, D, 3, 3, 1, 1, alloc=arx.alloc)
         ops.groupnorm_cl(conv, w[f"{pd}layer_{stage}.norm.weight"], w[f"{pd}layer_{stage}.norm.bias"], T, h * ww, D, 8,

@@ -153,6 +153,27 @@ def test_groupnorm(ops, T, HW, C, G, relu):
     close(out.view(T, HW, C).permute(0, 2, 1).reshape(T, C, HW, 1), ref, tol, tol * 0.1)
 
 
+@pytest.mark.parametrize("T,h,w,ho,wo,G", [(5, 45, 80, 90, 160, 8), (5, 23, 40, 45, 80, 8), (5, 12, 20, 23, 40, 8), (2, 6, 7, 13, 15, 32),
+                                           (1, 3, 3, 3, 3, 8)])
+def test_groupnorm_up_add_is_the_two_launches(ops, T, h, w, ho, wo, G):
+    """tce_groupnorm_up_add_f32 (round 5): the GroupNorm + ReLU of a coarse map applied WHILE it is up-sampled (nearest, to an
+    exact finer size: odd sizes, non-integer ratios) and added to the finer map -- the pixel decoder's top-down merge -- against
+    tce_groupnorm_f32 followed by tce_resize_nearest_f32: same arithmetic, bit-identical; and against torch; in place on add."""
+    C = 256
+    g = torch.Generator().manual_seed(h * w + ho)
+    x = torch.randn(T * h * w, C, generator=g) * 2 + 0.5
+    fine = torch.randn(T * ho * wo, C, generator=g)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    y = ops.groupnorm_cl(dev(x), dev(ga), dev(be), T, h * w, C, G, relu=True)
+    two = ops.resize_nearest(y, T, h, w, ho, wo, C, add=dev(fine))
+    one = dev(fine)
+    ops.groupnorm_up_add(dev(x), dev(ga), dev(be), T, h, w, ho, wo, C, G, add=one, out=one, relu=True)
+    assert torch.equal(one, two)
+    ref = F.relu(F.group_norm(x.double().view(T, h * w, C).permute(0, 2, 1).reshape(T, C, h, w), G, ga.double(), be.double(), 1e-5))
+    ref = fine.double().view(T, ho, wo, C) + F.interpolate(ref, size=(ho, wo), mode="nearest").permute(0, 2, 3, 1)
+    close(one.view(T, ho, wo, C), ref.float(), 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("T,H,W,C", [(2, 72, 100, 96), (1, 30, 41, 128), (1, 8, 8, 32), (5, 360, 640, 96), (1, 37, 50, 192),
                                      (2, 33, 64, 152)])
 def test_patch_embed(ops, T, H, W, C):
