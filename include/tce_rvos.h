@@ -225,6 +225,11 @@ int tce_resize_nearest_f32(const float* in, const float* add, float* out, int32_
                            int32_t wo, int32_t C, tceStream stream);
 int tce_resize_bilinear_f32(const float* in, const float* add, float* out, int32_t T, int32_t h, int32_t w,
                             int32_t ho, int32_t wo, int32_t C, tceStream stream);
+/* The same followed by a LayerNorm over the C = 256 channels of the sum, as ONE pass (round 5): out = LN(add + bilinear(in)) -- the
+ * VisionLanguageBlock's spatially reduced self-attention `tgt + interpolate(attn)` and its norm1 (segmentation.py:357-365).  Same
+ * operation sequence as tce_resize_bilinear_f32 followed by tce_layernorm_f32 (equal to a few ulp).  out may alias add (not in). */
+int tce_resize_bilinear_ln_f32(const float* in, const float* add, const float* gamma, const float* beta, float eps, float* out,
+                               int32_t T, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t C, tceStream stream);
 
 /* Elementwise helpers (tiny tensors of the decoder / heads):
  *   tce_add_f32        out = a + b (b broadcast with period nb elements)

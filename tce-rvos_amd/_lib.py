@@ -101,6 +101,7 @@ SIGNATURES = {
     "tce_pos_sine2d_valid_f32": (i32, [c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_nearest_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_resize_bilinear_f32": (i32, [c_f, c_f, c_f, i32, i32, i32, i32, i32, i32, c_f]),
+    "tce_resize_bilinear_ln_f32": (i32, [c_f, c_f, c_f, c_f, f32, c_f, i32, i32, i32, i32, i32, i32, c_f]),
     "tce_add_f32": (i32, [c_f, c_f, c_f, i64, i64, c_f]),
     "tce_tile_f32": (i32, [c_f, c_f, i64, i64, c_f]),
     "tce_sigmoid_f32": (i32, [c_f, c_f, i64, c_f]),

@@ -49,17 +49,12 @@ __global__ void __launch_bounds__(256) resize_nearest_kernel(const float* __rest
   reinterpret_cast<f32x4*>(out)[idx] = v;
 }
 
-__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in,
-                                                              const float* __restrict__ add, float* __restrict__ out,
-                                                              int T, int h, int w, int ho, int wo, int C4,
-                                                              long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c = (int)(idx % C4);
-  long long r = idx / C4;
-  const int xo = (int)(r % wo); r /= wo;
-  const int yo = (int)(r % ho);
-  const int t = (int)(r / ho);
+// four channels of output pixel (t, yo, xo) of F.interpolate(mode="bilinear", align_corners=False); one fixed sequence of
+// operations (no contraction left to the compiler) shared by the plain kernel and the fused resize + add + LayerNorm kernel, so the
+// two give the same bits
+__device__ __forceinline__ f32x4 bilinear4(const float* __restrict__ in, const int t, const int yo, const int xo, const int c,
+                                           const int h, const int w, const int ho, const int wo, const int C4) {
+#pragma clang fp contract(off)
   const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
   const float fy = fmaxf(sy * ((float)yo + 0.5f) - 0.5f, 0.f);
   const float fx = fmaxf(sx * ((float)xo + 0.5f) - 0.5f, 0.f);
@@ -72,9 +67,63 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __res
   const f32x4 v10 = i4[((long long)y1 * w + x0) * C4], v11 = i4[((long long)y1 * w + x1) * C4];
   f32x4 o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+  for (int j = 0; j < 4; ++j) {
+    const float top = __builtin_fmaf(lx, v01[j], hx * v00[j]), bot = __builtin_fmaf(lx, v11[j], hx * v10[j]);
+    o[j] = __builtin_fmaf(ly, bot, hy * top);
+  }
+  return o;
+}
+
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in,
+                                                              const float* __restrict__ add, float* __restrict__ out,
+                                                              int T, int h, int w, int ho, int wo, int C4,
+                                                              long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4);
+  long long r = idx / C4;
+  const int xo = (int)(r % wo); r /= wo;
+  const int yo = (int)(r % ho);
+  const int t = (int)(r / ho);
+  f32x4 o = bilinear4(in, t, yo, xo, c, h, w, ho, wo, C4);
   if (add) o += reinterpret_cast<const f32x4*>(add)[idx];
   reinterpret_cast<f32x4*>(out)[idx] = o;
+}
+
+// out[row, :] = LayerNorm(add[row, :] + bilinear(in)[row, :]) for C = 256: a wave per output pixel (64 lanes x 4 channels), the
+// statistics by xor-shuffles exactly as layernorm_reg_kernel<64> takes them -- the VisionLanguageBlock's spatially reduced
+// self-attention `tgt + interpolate(attention output)` followed by norm1 (segmentation.py:357-365) as ONE pass over the map (the two
+// launches read and write the [T*h*w, 256] map twice: 590 MB each way at stride 4 for an 8-clip group).  out may alias add.
+__global__ void __launch_bounds__(256) resize_bilinear_ln_kernel(const float* __restrict__ in, const float* add,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* out, int T, int h, int w, int ho, int wo, float eps,
+                                                                 long long rows) {
+  constexpr int C = 256, C4 = 64;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // (whole waves: the shuffles below stay inside a wave)
+  long long r = row;
+  const int xo = (int)(r % wo); r /= wo;
+  const int yo = (int)(r % ho);
+  const int t = (int)(r / ho);
+  f32x4 v = bilinear4(in, t, yo, xo, lane, h, w, ho, wo, C4);
+  v += reinterpret_cast<const f32x4*>(add + row * C)[lane];
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
+  float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[lane], bb = reinterpret_cast<const f32x4*>(beta)[lane];
+  f32x4 o;
+  o[0] = a * rstd * g[0] + bb[0];
+  o[1] = b * rstd * g[1] + bb[1];
+  o[2] = c * rstd * g[2] + bb[2];
+  o[3] = d * rstd * g[3] + bb[3];
+  reinterpret_cast<f32x4*>(out + row * C)[lane] = o;
 }
 
 __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -318,6 +367,21 @@ extern "C" int tce_resize_bilinear_f32(const float* in, const float* add, float*
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(tce_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, add,
                      out, T, h, w, ho, wo, C / 4, total);
   TCE_CHECK_LAUNCH("tce_resize_bilinear_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_resize_bilinear_ln_f32(const float* in, const float* add, const float* gamma, const float* beta, float eps,
+                                          float* out, int32_t T, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t C,
+                                          tceStream stream) {
+  TCE_CHECK_ARG(in && add && gamma && beta && out && T > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "tce_resize_bilinear_ln_f32: bad arguments");
+  TCE_CHECK_ARG(C == 256, "tce_resize_bilinear_ln_f32: C must be 256 (a wave per row)");
+  TCE_CHECK_ARG(tce_aligned16(in) && tce_aligned16(out) && tce_aligned16(add) && tce_aligned16(gamma) && tce_aligned16(beta),
+                "tce_resize_bilinear_ln_f32: pointers must be 16-byte aligned");
+  TCE_CHECK_ARG(in != out, "tce_resize_bilinear_ln_f32: out may alias add, not in");
+  const long long rows = (long long)T * ho * wo;
+  hipLaunchKernelGGL(resize_bilinear_ln_kernel, dim3(tce_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, in, add, gamma, beta, out,
+                     T, h, w, ho, wo, eps, rows);
+  TCE_CHECK_LAUNCH("tce_resize_bilinear_ln_f32");
   return TCE_OK;
 }
 

@@ -285,6 +285,12 @@ def _resize(a):
     return rd, [dense(_p(out), T * ho * wo * Cn * F)]
 
 
+def _resize_ln(a):
+    src, add, gamma, beta, _, out, T, h, w, ho, wo, Cn = a[:12]
+    return ([dense(_p(src), T * h * w * Cn * F), dense(_p(add), T * ho * wo * Cn * F), dense(_p(gamma), Cn * F), dense(_p(beta), Cn * F)],
+            [dense(_p(out), T * ho * wo * Cn * F)])
+
+
 def _win(a):
     qkv, qb, table, out, T, H, W, Cn, nH = a[:9]
     return ([dense(_p(qkv), T * H * W * 3 * Cn * F), dense(_p(qb), 3 * Cn * F)], [dense(_p(out), T * H * W * Cn * F)])
@@ -346,6 +352,7 @@ MODELS = {
     "tce_pos_sine2d_valid_f32": lambda a: _pos(a, True),
     "tce_resize_nearest_f32": _resize,
     "tce_resize_bilinear_f32": _resize,
+    "tce_resize_bilinear_ln_f32": _resize_ln,
     "tce_add_f32": lambda a: ([dense(_p(a[0]), a[3] * F), dense(_p(a[1]), a[4] * F)], [dense(_p(a[2]), a[3] * F)]),
     "tce_tile_f32": lambda a: ([dense(_p(a[0]), a[2] * F)], [dense(_p(a[1]), a[2] * a[3] * F)]),
     "tce_sigmoid_f32": lambda a: ([dense(_p(a[0]), a[2] * F)], [dense(_p(a[1]), a[2] * F)]),

@@ -639,10 +639,21 @@ def resize_nearest(x, T, h, w, ho, wo, Cn, add=None, out=None, alloc=None):
     return out
 
 
-def resize_bilinear(x, T, h, w, ho, wo, Cn, add=None, out=None, alloc=None):
+RESIZE_LN_FUSE = os.environ.get("TCE_RESIZE_LN_FUSE", "1") != "0"  # A/B: 0 = bilinear resize + add and the LayerNorm as two launches
+
+
+def resize_bilinear(x, T, h, w, ho, wo, Cn, add=None, out=None, alloc=None, ln=None, eps=1e-5):
+    """ln = (gamma, beta): out = LayerNorm(add + bilinear(x)) in one pass (tce_resize_bilinear_ln_f32; C = 256, add required)."""
     _chk(x, "x")
     if out is None:
         out = alloc(T * ho * wo, Cn) if alloc else torch.empty(T * ho * wo, Cn, dtype=torch.float32, device=x.device)
+    if ln is not None:
+        if Cn == 256 and add is not None and RESIZE_LN_FUSE:
+            check(lib().tce_resize_bilinear_ln_f32(x.data_ptr(), add.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), eps, out.data_ptr(),
+                                                   T, h, w, ho, wo, Cn, _stream()), "tce_resize_bilinear_ln_f32")
+            return out
+        resize_bilinear(x, T, h, w, ho, wo, Cn, add=add, out=out)
+        return layernorm(out, ln[0], ln[1], eps, out=out)
     check(lib().tce_resize_bilinear_f32(x.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), T, h,
                                         w, ho, wo, Cn, _stream()), "tce_resize_bilinear_f32")
     return out

@@ -1009,6 +1009,7 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
     bp = f"{pd}cross_attn_{stage}."
     pre = bp + "self_attn."
     red = sc["red"].get(stage)
+    normed = False
     with model.arith("pixel.attn"):
         m1 = arx.mark()
         if red is not None:  # spatial-reduction self-attention (segmentation.py:333-361)
@@ -1024,7 +1025,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
             ops.mha_core(qk, qk[:, D:], v, G, NH, nc, nc, 2 * D, 2 * D, D, nc * 2 * D, nc * 2 * D, nc * D, att, D, nc * D, alloc=A,
                          kmask=sc["kmask"].get(stage))  # padded clips: padded positions are no keys (segmentation.py:345-356)
             o_low = _lin(A, att, n_low, D, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"], D)
-            ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt)
+            ops.resize_bilinear(o_low, T, nh_, nw_, h, ww, D, add=tgt, out=tgt, ln=(w[bp + "norm1.weight"], w[bp + "norm1.bias"]))
+            normed = True  # norm1 rode in the resize + add pass
         else:
             n = T * hw
             qk = A(n, 2 * D)
@@ -1038,7 +1040,8 @@ def _lateral(model, sc, feats, memory, vl_sites, T, L, ffn, ln_, stage, arx, G=1
             gemm_ex(att, w[pre + "out_proj.weight"], tgt, n, D, D, D, D, D, bias=w[pre + "out_proj.bias"], res=tgt,
                     ldres=D, res_mode=RES_ADD)
         arx.release(m1)
-    ln_(tgt, bp + "norm1")
+    if not normed:
+        ln_(tgt, bp + "norm1")
     # text cross-attention (:366-371)
     pre = bp + "multihead_attn."
     with model.arith("pixel.xattn"):

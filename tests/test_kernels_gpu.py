@@ -174,6 +174,26 @@ def test_groupnorm_up_add_is_the_two_launches(ops, T, h, w, ho, wo, G):
     close(one.view(T, ho, wo, C), ref.float(), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("T,h,w,ho,wo", [(5, 12, 20, 90, 160), (5, 12, 20, 45, 80), (2, 12, 20, 23, 40), (3, 5, 7, 11, 13), (1, 1, 1, 3, 2)])
+def test_resize_bilinear_ln_is_the_two_launches(ops, T, h, w, ho, wo):
+    """tce_resize_bilinear_ln_f32 (round 5): LayerNorm(add + bilinear up-sampling) as one pass against tce_resize_bilinear_f32 then
+    tce_layernorm_f32 -- the same operation sequence up to the compiler's choice of fused multiply-adds in the two kernels'
+    LayerNorm arithmetic: equal to a few ulp -- and against torch (align_corners=False); in place on add."""
+    C = 256
+    g = torch.Generator().manual_seed(h * w + ho)
+    low = torch.randn(T * h * w, C, generator=g)
+    fine = torch.randn(T * ho * wo, C, generator=g) * 2 + 0.3
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    two = ops.resize_bilinear(dev(low), T, h, w, ho, wo, C, add=dev(fine))
+    two = ops.layernorm(two, dev(ga), dev(be), out=two)
+    one = dev(fine)
+    ops.resize_bilinear(dev(low), T, h, w, ho, wo, C, add=one, out=one, ln=(dev(ga), dev(be)))
+    assert float((one - two).abs().max()) <= 4e-6 * float(two.abs().max())
+    up = F.interpolate(low.double().view(T, h, w, C).permute(0, 3, 1, 2), size=(ho, wo), mode="bilinear", align_corners=False)
+    ref = F.layer_norm(fine.double().view(T, ho, wo, C) + up.permute(0, 2, 3, 1), (C,), ga.double(), be.double(), 1e-5)
+    close(one.view(T, ho, wo, C), ref.float(), 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("T,H,W,C", [(2, 72, 100, 96), (1, 30, 41, 128), (1, 8, 8, 32), (5, 360, 640, 96), (1, 37, 50, 192),
                                      (2, 33, 64, 152)])
 def test_patch_embed(ops, T, H, W, C):
