@@ -184,3 +184,20 @@ def test_arith_override_is_per_thread():
         assert seen["mode"] == "f16" and seen["after"] == "f16"
     finally:
         ops.set_gemm_mode("f16x3")
+
+
+def test_ffn_split_plan_is_the_calibrated_one(built_lib):
+    """tce_ffn_split_ws_floats / tce_ffn_split_counters (host-side planning, no launch): the hidden-extent split of the fused FFN is
+    planned where the measurements say it pays -- launches of 1.1 .. 1.3 rounds of 256 CUs and single partial rounds cut 1 -> 2 or
+    2 -> 3 -- and NOT for config 2's 24100-row encoder launches (3 -> 4: measured slower in the clip), full-round launches, other
+    widths or GELU."""
+    from tce_rvos_amd import _lib
+    l = _lib.lib()
+    for M, planned in ((24100, False), (72000, False), (192800, False), (85570, False), (18000, True), (40800, True), (16000, True)):
+        ws, cnt = l.tce_ffn_split_ws_floats(M, 256, 2048, 1), l.tce_ffn_split_counters(M, 256, 2048, 1)
+        if planned:
+            assert cnt == (M + 127) // 128 and ws == cnt * 2 * 128 * 256, (M, ws, cnt)
+        else:
+            assert (ws, cnt) == (0, 0), (M, ws, cnt)
+    assert l.tce_ffn_split_ws_floats(18000, 192, 768, 2) == 0 and l.tce_ffn_split_ws_floats(18000, 256, 2048, 2) == 0
+    assert l.tce_ffn_split_ws_floats(0, 256, 2048, 1) == 0
