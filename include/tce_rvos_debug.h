@@ -14,6 +14,9 @@ int tce_debug_set_stamp_buffer(long long* dev_buf);
 int tce_debug_set_epilogue(int32_t lds_staged);
 /* register (or clear with NULL) a device buffer of >= 1024*8 int64 for the fused FFN's in-kernel stamps */
 int tce_debug_ffn_set_stamp_buffer(long long* dev_buf);
+/* tuning aid: the C <= 128 fused MLP as 128-row workgroups, two per CU (same packed stream): 0 = by the launch's round count
+ * (default), 1 = always, -1 = never */
+int tce_debug_ffn_set_half(int32_t mode);
 /* tuning aid: 1 = tce_msda_fused_f32 uses its LDS-staged form for encoder-sized calls (A/B timing, bit-identity
  * tests); 0 = default (measured not faster than the L2-gather form) */
 int tce_debug_msda_set_lds(int32_t on); /* 0 default (= 4); 1 LDS-staged; 2 one point at a time; 3 / 4: two / four points in flight */

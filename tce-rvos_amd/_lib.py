@@ -154,6 +154,7 @@ DEBUG_SIGNATURES = {
     "tce_debug_set_stamp_buffer": (i32, [c_f]),
     "tce_debug_set_epilogue": (i32, [i32]),
     "tce_debug_ffn_set_stamp_buffer": (i32, [c_f]),
+    "tce_debug_ffn_set_half": (i32, [i32]),
     "tce_debug_msda_set_lds": (i32, [i32]),
     "tce_debug_window_attn_set_mfma": (i32, [i32]),
     "tce_debug_mha_set_split": (i32, [i32]),

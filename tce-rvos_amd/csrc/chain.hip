@@ -330,17 +330,25 @@ struct FfnArgs {
 // scheduler from overlapping a step's loads, DMA and split with its MFMAs: 192 -> 175 us at 24100 rows, 90 -> 79 us for the
 // C = 192 instantiation, the config-2 clip 6.87 -> 6.63 ms (A/B in one call, profiles/r04_single_template.txt).
 template <int C, int WAVES, int ACT, bool SINGLE, int ACT2 = 0, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const FfnArgs p) {
+__global__ void __launch_bounds__(64 * WAVES, (WAVES == 4 && C <= 128) ? 2 : WAVES / 4) ffn_fused_kernel(const FfnArgs p) {
   static_assert(!(SPLIT && ACT2 != 0), "a chain is not split");
   constexpr int KS = C / 16, NT = C / 32;
-  constexpr int SLOTS = (1 + 2 * KS + 4 * NT + WAVES - 1) / WAVES;
-  constexpr int P = SLOTS * WAVES;  // pieces per stage, padded so that every wave issues exactly SLOTS DMAs (no branches)
+  // HALF (round 5): the C <= 128 kernels (packed for 8 waves = 256 rows per workgroup) as 128-row workgroups, TWO per CU, reading the
+  // same stream.  72000 rows are 282 workgroups of 256 rows = 1.1 rounds of the chip that cost two; as 563 half workgroups the 51 of
+  // the second round run one wave per SIMD and finish in half a round (ffn_launch picks per launch).  Its staging tiles alias ring
+  // stage 1: they are used before the loop (stage 0 is being filled) and after it (both stages drained), never inside.
+  constexpr bool HALF = WAVES == 4 && C <= 128;
+  constexpr int PWAVES = HALF ? 8 : WAVES;  // the stream's padding unit
+  constexpr int P = (1 + 2 * KS + 4 * NT + PWAVES - 1) / PWAVES * PWAVES;  // pieces per stage, padded so that every wave issues exactly SLOTS DMAs (no branches)
+  constexpr int SLOTS = P / WAVES;
+  static_assert(!(HALF && (SPLIT || ACT2 != 0)), "the half form is the plain kernel");
   constexpr int STAGE = P * PIECE;
   constexpr int STEPS = KS + 2 * NT;
   static_assert(SLOTS <= STEPS, "more DMA slots than loop steps");
-  static_assert(2 * STAGE + WAVES * WT_BYTES <= 160 * 1024, "ring + staging tiles do not fit the LDS");
+  static_assert(2 * STAGE + (HALF ? 0 : WAVES * WT_BYTES) <= (HALF ? 80 : 160) * 1024, "ring + staging tiles do not fit the LDS");
+  static_assert(!HALF || WAVES * WT_BYTES <= STAGE, "the half form's staging tiles alias one ring stage");
   // the ONLY LDS object (base offset 0): two ring stages, then one staging tile per wave
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + WAVES * WT_BYTES + (SPLIT ? 16 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + (HALF ? 0 : WAVES * WT_BYTES) + (SPLIT ? 16 : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -381,7 +389,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) ffn_fused_kernel(const 
   const float* const resb = p.res ? p.res + blockIdx.y * p.sRes : xb;
   const long long ldres = p.res ? p.ldres : p.ldx;
   float* const outb = p.out + blockIdx.y * p.sOut;
-  float* const wt = reinterpret_cast<float*>(smem + 2 * STAGE + wave * WT_BYTES);
+  float* const wt = reinterpret_cast<float*>(smem + (HALF ? STAGE : 2 * STAGE) + wave * WT_BYTES);
   tce_amax_t amax = 0;
   constexpr int single = SINGLE;
   // SPLIT: workgroup i of a group of sp_p + 1 runs the head [0, k_i) of the group's block i, then the tail [k_(i-1), NC) of block
@@ -1058,6 +1066,8 @@ inline FfnSplitPlan ffn_split_plan(int M, int C, int Hd, int batch) {
   return best;
 }
 
+static int g_ffn_half = 0;  // tce_debug_ffn_set_half: 0 automatic, 1 always (C <= 128), -1 never
+
 template <int C, int WAVES>
 void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
   if constexpr (C == 256) {
@@ -1065,6 +1075,22 @@ void ffn_launch(const FfnArgs& a, int act, hipStream_t s, int batch = 1) {
       const dim3 grid(tce_cdiv(a.nblk, a.sp_p) * (a.sp_p + 1), batch), block(64 * WAVES);
       if (a.single) hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, true, 0, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((ffn_fused_kernel<C, WAVES, 1, false, 0, true>), grid, block, 0, s, a);
+      return;
+    }
+  }
+  if constexpr (C <= 128 && WAVES == 8) {
+    // 256-row workgroups or 128-row ones, two per CU (HALF, same stream): by the rounds each form needs -- a last round of at most
+    // 256 half workgroups runs one wave per SIMD and costs half a round.  Ties go to the half form (tools/ffn_bench.py: 72000 x 96
+    // 92.7 -> 67.4 us, where it saves half a round; 122880 x 96 93.9 -> 88.8, 256800 x 128 279 -> 265, 36000 x 96 42.1 -> 42.3 us
+    // at equal round counts)
+    const long long b8 = (long long)tce_cdiv(a.M, 256) * batch, b4 = (long long)tce_cdiv(a.M, 128) * batch;
+    const double c8 = (double)((b8 + 255) / 256);
+    const long long rem = b4 % 512;
+    const double c4 = (double)(b4 / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 0.5 : 1.0);
+    if (act == 2 && g_ffn_half >= 0 && (g_ffn_half > 0 || c4 <= c8)) {
+      const dim3 grid(tce_cdiv(a.M, 128), batch), block(256);
+      if (a.single) hipLaunchKernelGGL((ffn_fused_kernel<C, 4, 2, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ffn_fused_kernel<C, 4, 2, false>), grid, block, 0, s, a);
       return;
     }
   }
@@ -1673,6 +1699,12 @@ extern "C" int tce_ffn_fused_f32(const float* x, int64_t ldx, const void* packed
   else if (C == 128) ffn_launch<128, 8>(a, act, s);
   else ffn_launch<96, 8>(a, act, s);
   TCE_CHECK_LAUNCH("tce_ffn_fused_f32");
+  return TCE_OK;
+}
+
+extern "C" int tce_debug_ffn_set_half(int32_t mode) {
+  TCE_CHECK_ARG(mode >= -1 && mode <= 1, "tce_debug_ffn_set_half: -1 (never), 0 (automatic) or 1 (always)");
+  g_ffn_half = mode;
   return TCE_OK;
 }
 

@@ -962,6 +962,34 @@ def test_ffn_fused_split(ops, M, ln, plan):
     ops.check_range()
 
 
+@pytest.mark.parametrize("M,C,Hd", [(72000, 96, 384), (3000, 96, 384), (20001, 128, 512)])
+def test_ffn_fused_half_workgroups_are_bit_identical(ops, M, C, Hd):
+    """The C <= 128 fused MLP as 128-row workgroups, two per CU, on the same packed stream (round 5; chosen by the launch's round
+    count: 72000 rows are 1.1 rounds of 256-row workgroups that cost two): same arithmetic per row -- bit-identical to the 256-row
+    form, LayerNorm prologue, GELU, ragged last block, in place."""
+    from tce_rvos_amd._lib import lib
+    g = torch.Generator().manual_seed(M + C)
+    x = dev(torch.randn(M, C, generator=g))
+    w1, b1 = torch.randn(Hd, C, generator=g) / math.sqrt(C), torch.randn(Hd, generator=g) * 0.2
+    w2, b2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd), torch.randn(C, generator=g) * 0.2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    pk = ops.ffn_pack(dev(w1), dev(b1), dev(w2))
+    outs = {}
+    for mode in (-1, 1):
+        lib().tce_debug_ffn_set_half(mode)
+        try:
+            o = x.clone()
+            ops.ffn_fused(o, pk, dev(b2), Hd, ops.ACT_GELU, ln_in=(dev(gam), dev(bet)))
+            outs[mode] = o
+        finally:
+            lib().tce_debug_ffn_set_half(0)
+    assert torch.equal(outs[-1], outs[1])
+    xr = x[:256].double().cpu()
+    ref = xr + F.linear(F.gelu(F.linear(F.layer_norm(xr, (C,), gam.double(), bet.double(), 1e-5), w1.double(), b1.double())), w2.double(), b2.double())
+    close(outs[1][:256], ref.float(), 2e-4, 2e-4)
+    ops.check_range()
+
+
 def test_ffn_fused_rejects_bad_arguments(ops):
     from tce_rvos_amd._lib import TceError
     with pytest.raises(ValueError):

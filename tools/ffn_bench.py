@@ -6,7 +6,7 @@ from tce_rvos_amd import ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="24100x256x2048:relu:out,72000x256x2048:relu:out,18000x256x2048:relu:out,40800x256x2048:relu:out,4600x256x2048:relu:out,"
-                                    "72000x96x384:gelu:in,18000x192x768:gelu:in")
+                                    "72000x96x384:gelu:in,18000x192x768:gelu:in,122880x96x384:gelu:in,256800x128x512:gelu:in")
 ap.add_argument("--iters", type=int, default=20)
 a = ap.parse_args()
 torch.manual_seed(0)
@@ -73,6 +73,14 @@ for spec in a.shapes.split(","):
     t_f = timeit(lambda: ops.ffn_fused(x, pk, b2, Hd, act, ln_in=ln_in, ln_out=ln_out, out=out), a.iters)
     t_u = timeit(unfused, a.iters)
     fl = 4.0 * M * C * Hd
+    if C <= 128:  # 256-row workgroups against 128-row ones, two per CU (tce_debug_ffn_set_half)
+        from tce_rvos_amd._lib import lib
+        res = {}
+        for mode in (-1, 1):
+            lib().tce_debug_ffn_set_half(mode)
+            res[mode] = timeit(lambda: ops.ffn_fused(x, pk, b2, Hd, act, ln_in=ln_in, ln_out=ln_out, out=out), a.iters)
+        lib().tce_debug_ffn_set_half(0)
+        print(f"{'':32s} 256-row workgroups {res[-1]:8.1f} us   128-row, two per CU {res[1]:8.1f} us")
     nws, ncnt = ops.ffn_split_need(M, C, Hd, act) if (act == 1 and ln_in is None) else (0, 0)
     if nws:  # the hidden-extent split planned for this shape
         ws, cnt = torch.empty(nws, device=dev), torch.zeros(ncnt, dtype=torch.int32, device=dev)
