@@ -165,6 +165,9 @@ def main():
     if os.environ.get("TCE_GEMM_TILE_RULES") == "r4":  # A/B aid (tools/runs/): tile selection by the previous round's rules
         from tce_rvos_amd._lib import lib as _l
         _l().tce_gemm_force_tile(-1)
+    if os.environ.get("TCE_CONV3_FORM"):  # A/B aid: 4 / 8 = one form of the 3x3 convolution everywhere (no mixed launches)
+        from tce_rvos_amd._lib import lib as _l
+        _l().tce_debug_conv3x3_set_waves(int(os.environ["TCE_CONV3_FORM"]))
     if os.environ.get("TCE_FFN_HALF"):  # A/B aid: -1 = the C <= 128 fused MLP never as half workgroups, 1 = always
         from tce_rvos_amd._lib import lib as _l
         _l().tce_debug_ffn_set_half(int(os.environ["TCE_FFN_HALF"]))

@@ -1274,6 +1274,7 @@ struct ConvArgs {
   int H, W, M;
   int* range_flag;
   int single;
+  int m_off;  // first pixel of this launch (a launch may cover a row range [m_off, ...) of the map: the mixed form below)
 };
 
 // Ablation builds (tools/conv3_ablate.py, -DCONV_ABL=n; results are then wrong): bit 0: one workgroup per CU; bit 1: no
@@ -1320,7 +1321,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) conv3x3_kernel(const Co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hf = lane >> 5;
-  const int m0 = blockIdx.x * (32 * WAVES) + wave * 32;
+  const int m0 = p.m_off + blockIdx.x * (32 * WAVES) + wave * 32;
 
   // this lane's pixel; per (vertical tap, chunk group) the addresses of its three horizontal neighbours' channels, or
   // of the zero block behind the weights for taps outside the image
@@ -1942,6 +1943,20 @@ extern "C" int tce_conv3x3_f32(const float* x, int64_t ldx, const void* packed, 
   static const int env_force = []() { const char* e = getenv("TCE_CONV3_WAVES"); return e ? atoi(e) : 0; }();
   const int force = g_conv3_waves ? g_conv3_waves : env_force;
   const int r4 = tce_cdiv(tce_cdiv(a.M, 128), 256), r8 = tce_cdiv(tce_cdiv(a.M, 256), 256);
+  a.m_off = 0;
+  // Mixed form (round 5): full rounds of 256-pixel workgroups, then the REMAINDER as 128-pixel workgroups (they run one wave per
+  // SIMD: a round of them costs 1 against 1.75).  72000 px: 256 wide workgroups + 51 narrow ones = 1.75 + 1 rounds against 3 narrow
+  // rounds (or 2 x 1.75 wide ones).  In units of a narrow round x 4:
+  const int full8 = tce_cdiv(a.M, 256) / 256;                       // complete rounds of wide workgroups
+  const int rem_px = a.M - full8 * 256 * 256;
+  const int mixed4 = 7 * full8 + 4 * tce_cdiv(tce_cdiv(rem_px, 128), 256);
+  if (!force && !a.single && full8 >= 1 && rem_px > 0 && mixed4 < 4 * r4 && mixed4 < 7 * r8) {
+    hipLaunchKernelGGL((conv3x3_kernel<256, false, 8>), dim3(full8 * 256), dim3(512), 0, (hipStream_t)stream, a);
+    a.m_off = full8 * 256 * 256;
+    hipLaunchKernelGGL((conv3x3_kernel<256, false>), dim3(tce_cdiv(rem_px, 128)), dim3(256), 0, (hipStream_t)stream, a);
+    TCE_CHECK_LAUNCH("tce_conv3x3_f32(mixed)");
+    return TCE_OK;
+  }
   const int wide = force ? force : (4 * r4 > 7 * r8 ? 8 : 4);
   if (wide == 8 && !a.single) hipLaunchKernelGGL((conv3x3_kernel<256, false, 8>), dim3(tce_cdiv(a.M, 256)), dim3(512), 0, (hipStream_t)stream, a);
   else if (a.single) hipLaunchKernelGGL((conv3x3_kernel<256, true>), dim3(tce_cdiv(a.M, 128)), dim3(256), 0, (hipStream_t)stream, a);

@@ -1334,9 +1334,10 @@ def test_copy_segments_plan_and_many(ops):
         ops.CopyPlan([base[:100:3]])  # neither dense nor a row gather
 
 
-@pytest.fixture(params=[4, 8])
+@pytest.fixture(params=[4, 8, 0])
 def conv_waves(request):
-    """Both forms of the pixel-stationary convolution: 128-pixel (4-wave) and 256-pixel (8-wave, round 5) workgroups."""
+    """The forms of the pixel-stationary convolution: 128-pixel (4-wave) workgroups, 256-pixel (8-wave, round 5) ones, and the
+    launcher's own choice (0) -- at 72000 pixels the mixed form: one round of 256-pixel workgroups, the remainder as 128-pixel ones."""
     from tce_rvos_amd._lib import lib
     lib().tce_debug_conv3x3_set_waves(request.param)
     yield request.param
