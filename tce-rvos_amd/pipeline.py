@@ -56,6 +56,7 @@ TEXT_EARLY_EDGE = os.environ.get("TCE_TEXT_EARLY_EDGE", "0") != "0"
 EARLY_PROJ = os.environ.get("TCE_EARLY_PROJ", "1") != "0"
 TOKFORK = os.environ.get("TCE_TOKFORK", "1") != "0"
 ENCFORK = os.environ.get("TCE_ENCFORK", "1") != "0"
+DEFER_OUT_NORM = os.environ.get("TCE_DEFER_OUT_NORM", "1") != "0"  # A/B: 0 = every Swin stage's output norm on the backbone's own stream
 LAT1_AT = os.environ.get("TCE_LAT1_AT")
 SWIN3_FC2_SPLITK = int(os.environ.get("TCE_SWIN3_FC2_SPLITK", 2))
 # norm1 / norm2 of the frame-token path in the prologue of the few-row launch that follows them (8 launches fewer per clip): measured
@@ -355,18 +356,28 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         hw_i = sizes[i][0] * sizes[i][1]
         return feat[select * hw_i:(select + 1) * hw_i]
 
-    def on_stage(i, feat):
+    pending_norm0 = []  # stage 0's output norm, applied at the head of the stride-4 lateral branch (start_lat1)
+
+    def on_stage(i, feat, finish=None):
         if i == 0 and text_late:
             text_stage()
+        if i == 0 and finish is not None:
+            pending_norm0.append(finish)
         feat = pick(feat, i)
         if early:
             if i in (1, 2):
                     arx, stx = fork3[i - 1]
                     fk_ = _Fork(stx)
                     with fk_:
+                        if finish is not None:
+                            finish()  # the stage's output norm, in this branch
                         text_fork.join()  # this level's stream waits for the text branch (keys / values of the fusion)
                         input_level(i - 1, feat, arx.alloc)
                     lvl_forks.append(fk_)
+    if DEFER_OUT_NORM:
+        # stage 0's map is read by the stride-4 lateral branch only (started later, on its own stream); stages 1 / 2 by their
+        # level's early input projection (forked right here); stage 3 by the main stream itself
+        on_stage.defers = lambda i: select is None and ((i == 0 and ar2 is not None and stream2 is not None) or (i in (1, 2) and early))
     if cfg.is_resnet:
         with model.arith("backbone.merge"):  # a ResNet is convolutions only: one site group
             feats = _resnet_backbone(model, frames, ar, sizes, rep=G if shared else 1)
@@ -386,6 +397,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
         ar2.reset()
         lat1_fork = _Fork(stream2)
         with lat1_fork:
+            while pending_norm0:
+                pending_norm0.pop()()  # Swin stage 0's output norm, here where its only consumer runs
             return (lat1_fork, _lateral(model, sc, feats, None, vl_sites, T, L, ffn, ln_, 1, ar2, G))
     # When it starts is a trade: its long kernels (72000-row cross-attention, FFN, GEMMs) slow down whatever runs beside
     # them, and it must be done when the chain reaches stride 4.  Measured at config 2 (ms per clip): right after Swin
@@ -783,6 +796,8 @@ def _run_clip(model, frames, text, img_h, img_w, ar, side_arena=None, side_strea
 
     _stage("decoder fork")
     # ------------------------------------------------------------------ pixel decoder (segmentation.py:175-296)
+    while pending_norm0:  # (the stride-4 lateral branch was never started: its input's norm runs here, before the decoder reads it)
+        pending_norm0.pop()()
     mask_feats = _pixel_decoder(model, ar, sc, feats, memory, vl_sites, T, L, ffn, ln_, lat1=lat1, par=fork3, G=G)
     dec_fork.join()
 
@@ -916,13 +931,23 @@ def _swin_backbone(model, frames, ar, sizes, on_stage=None, G=1, rep=1):
             ar.release(m0)
         if cfg.video:
             feats.append(x if rep == 1 else ops.tile(x, rep, out=out_i))
+            finish = None
         else:
-            ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i[:ntok])
-            if rep > 1:
-                ops.tile(out_i[:ntok], rep - 1, out=out_i[ntok:])
+            def finish(x=x, i=i, out_i=out_i, ntok=ntok):
+                """the stage's OUTPUT norm (swin_transformer.py:608-611): only the consumers of the map need it, the next stage reads
+                the un-normed x"""
+                ops.layernorm(x, w[f"{b}norm{i}.weight"], w[f"{b}norm{i}.bias"], out=out_i[:ntok])
+                if rep > 1:
+                    ops.tile(out_i[:ntok], rep - 1, out=out_i[ntok:])
+            # a consumer that runs as a parallel branch applies it there (off the backbone's critical path: 8-10 us per stage)
+            if on_stage is not None and getattr(on_stage, "defers", None) is not None and on_stage.defers(i):
+                pass
+            else:
+                finish()
+                finish = None
             feats.append(out_i)
         if on_stage is not None:
-            on_stage(i, feats[-1])  # the stage's map is final: work that needs only this map may start beside the rest
+            on_stage(i, feats[-1], finish)  # the stage's map is final (or its norm handed over): work that needs only this map may start
         if x_next is not None:
             m0 = ar.mark()
             p = f"{b}downsamples.{i}." if cfg.video else f"{b}layers.{i}.downsample."
