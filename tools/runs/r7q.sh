@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5, call 7q: 3 -> 4 hidden-extent split for fused-FFN launches of more than one round (72000 rows: the stride-4 lateral branch), A/B
+# (the TCE_FFN_SPLIT_MULTI switch existed only in the build this script measured: the 3 -> 4 plan for multi-round launches was slower and was removed)
 O=gpurun_out/r7q; mkdir -p $O
 B="--no-cpu-baseline --no-roofline --no-variants"
 for rep in 1 2 3; do for c in 1 0; do

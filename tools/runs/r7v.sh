@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5, call 7v: ring depth of the token-stationary linear kernel where one workgroup owns the CU (ROW mode, K > 256): 5 slots against 3
 # (two builds: lib/libtce_rvos.so and lib/libtce_rvos_ring3.so = HIPCC_EXTRA=-DROWLIN_RING_DEEP=3, selected with TCE_LIB)
+# (the 5-slot build is not in the tree any more: it was slower; rebuild it with -DROWLIN_RING_DEEP=5 on the commit before "deeper rowlin ring measured slower")
 O=gpurun_out/r7v; mkdir -p $O
 R3=$GRAFT_REPO_ROOT/tce-rvos_amd/lib/libtce_rvos_ring3.so
 timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "rowlin" > $O/k.log 2>&1; rc=$?; echo "kernel rc=$rc"; tail -3 $O/k.log
