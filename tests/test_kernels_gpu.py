@@ -990,6 +990,40 @@ def test_ffn_fused_half_workgroups_are_bit_identical(ops, M, C, Hd):
     ops.check_range()
 
 
+def test_round_count_forms_at_boundary_sizes(ops):
+    """The launch forms chosen by round counts (round 5) at sizes around their decision boundaries: the 3x3 convolution's mixed
+    launches (complete rounds of 256-pixel workgroups + a remainder of 128-pixel ones) against the 128-pixel form everywhere, and
+    the C = 96 fused MLP's own choice against the 256-row form -- bit-identical in both cases, ragged last blocks included."""
+    from tce_rvos_amd._lib import lib
+    g = torch.Generator().manual_seed(99)
+    w_cl = dev(torch.randn(256, 2304, generator=g) / 48.0)
+    pk = ops.conv3x3_pack(w_cl, 256)
+    for (T, H, W) in ((1, 256, 256), (1, 257, 256), (1, 255, 257), (2, 256, 257), (1, 300, 301)):   # 65536 px = one wide round exactly, +-
+        x = dev(torch.randn(T * H * W, 256, generator=g))
+        auto = ops.conv3x3(x, pk, T, H, W, 256, 256)
+        lib().tce_debug_conv3x3_set_waves(4)
+        try:
+            narrow = ops.conv3x3(x, pk, T, H, W, 256, 256)
+        finally:
+            lib().tce_debug_conv3x3_set_waves(0)
+        assert torch.equal(auto, narrow), (T, H, W)
+    w1, b1 = torch.randn(384, 96, generator=g) / 10, torch.randn(384, generator=g) * 0.2
+    w2, b2 = torch.randn(96, 384, generator=g) / 20, torch.randn(96, generator=g) * 0.2
+    pkf = ops.ffn_pack(dev(w1), dev(b1), dev(w2))
+    for M in (65536, 65537, 65535 + 256, 131072 + 5, 32768 - 3, 98304 + 130):
+        x = dev(torch.randn(M, 96, generator=g))
+        auto = x.clone()
+        ops.ffn_fused(auto, pkf, dev(b2), 384, ops.ACT_GELU)
+        lib().tce_debug_ffn_set_half(-1)
+        try:
+            wide = x.clone()
+            ops.ffn_fused(wide, pkf, dev(b2), 384, ops.ACT_GELU)
+        finally:
+            lib().tce_debug_ffn_set_half(0)
+        assert torch.equal(auto, wide), M
+    ops.check_range()
+
+
 def test_ffn_fused_rejects_bad_arguments(ops):
     from tce_rvos_amd._lib import TceError
     with pytest.raises(ValueError):
